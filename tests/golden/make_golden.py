@@ -1,0 +1,404 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference; the GPU box has none).
+The reference's own modules (mvp_gan/src/models/{pconv,generator,discriminator}.py and
+mvp_gan/src/utils/losses.py) are imported by file path under a synthetic parent package
+(SURVEY.md §8c recipe); `torchvision` is absent here, so a stub exposes `vgg16(weights=...)`
+returning the standard VGG16-D `features` Sequential with nn.Conv2d default init (deterministic
+stand-in weights: the ImageNet weights are not fetchable offline).
+
+Nothing of the reference's source is written out: fixtures hold inputs (or the seed that makes
+them) and expected outputs only.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import importlib.util
+import io
+import logging
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from oracle.terragan_oracle import synth_batch  # noqa: E402  (input recipe only)
+
+logging.disable(logging.CRITICAL)
+torch.set_num_threads(8)
+
+
+def _load_reference():
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+
+    class VGG16_Weights:  # noqa: N801
+        IMAGENET1K_V1 = "standin"
+
+    def vgg16(weights=None):
+        cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+        layers, cin = [], 3
+        for v in cfg:
+            if v == "M":
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        m = nn.Module()
+        m.features = nn.Sequential(*layers)
+        return m
+
+    tvm.vgg16, tvm.VGG16_Weights = vgg16, VGG16_Weights
+    tv.models = tvm
+    sys.modules["torchvision"], sys.modules["torchvision.models"] = tv, tvm
+
+    for pkg in ["refpkg", "refpkg.models", "refpkg.utils"]:
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+
+    def load(modname, rel):
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    pconv = load("refpkg.models.pconv", "mvp_gan/src/models/pconv.py")
+    gen = load("refpkg.models.generator", "mvp_gan/src/models/generator.py")
+    disc = load("refpkg.models.discriminator", "mvp_gan/src/models/discriminator.py")
+    losses = load("refpkg.utils.losses", "mvp_gan/src/utils/losses.py")
+    return pconv, gen, disc, losses
+
+
+def summ(t, full_limit=20000):
+    """Full tensor when small, else (sum, abs-sum, l2, strided sample) in float64."""
+    t = t.detach().double().flatten()
+    if t.numel() <= full_limit:
+        return {"full": t.float().numpy()}
+    stride = max(1, t.numel() // 512)
+    return {"sum": np.float64(t.sum()), "abssum": np.float64(t.abs().sum()),
+            "l2": np.float64(t.norm()), "stride": np.int64(stride),
+            "sample": t[::stride][:512].float().numpy()}
+
+
+def put(out, name, t, **kw):
+    for k, v in summ(t, **kw).items():
+        out[f"{name}/{k}"] = v
+
+
+def mask_case(kind, b, h, w, g):
+    m = torch.ones(b, 1, h, w)
+    if kind == "ones":
+        pass
+    elif kind == "zeros":
+        m.zero_()
+    elif kind == "holes30":
+        m = (torch.rand(b, 1, h, w, generator=g) > 0.3).float()
+    elif kind == "single":
+        m.zero_()
+        m[:, :, h // 2, w // 3] = 1
+    elif kind == "border":
+        m.zero_()
+        m[:, :, 0, :] = 1
+        m[:, :, -1, :] = 1
+        m[:, :, :, 0] = 1
+        m[:, :, :, -1] = 1
+    elif kind == "blocks":
+        m = (torch.rand(b, 1, (h + 3) // 4, (w + 3) // 4, generator=g) > 0.4).float()
+        m = m.repeat_interleave(4, 2).repeat_interleave(4, 3)[:, :, :h, :w].contiguous()
+    return m
+
+
+PCONV_CASES = [  # (cin, cout, k, s, p, B, H, W)
+    (1, 64, 7, 2, 3, 2, 24, 24),
+    (64, 128, 5, 2, 2, 2, 24, 24),
+    (256, 512, 3, 2, 1, 2, 12, 12),
+    (192, 64, 3, 1, 1, 2, 16, 16),
+    (64, 64, 3, 1, 1, 2, 24, 20),
+    (32, 32, 3, 2, 1, 3, 9, 11),      # odd sizes
+]
+MASK_KINDS = ["ones", "zeros", "holes30", "single", "border", "blocks"]
+
+
+def gen_pconv(ref_pconv):
+    out = {}
+    for ci, (cin, cout, k, s, p, b, h, w) in enumerate(PCONV_CASES):
+        for kind in MASK_KINDS:
+            tag = f"c{ci}_{kind}"
+            torch.manual_seed(100 + ci)
+            layer = ref_pconv.PConv2d(cin, cout, k, s, p)
+            with torch.no_grad():          # non-trivial BN affine
+                layer.bn.weight.uniform_(0.5, 1.5)
+                layer.bn.bias.uniform_(-0.3, 0.3)
+            g = torch.Generator().manual_seed(200 + ci)
+            x = torch.randn(b, cin, h, w, generator=g, requires_grad=True)
+            m = mask_case(kind, b, h, w, g)
+            y, mo = layer(x, m)
+            gy = torch.randn(y.shape, generator=g)
+            (y * gy).sum().backward()
+            out[f"{tag}/cfg"] = np.array([cin, cout, k, s, p, b, h, w], dtype=np.int64)
+            put(out, f"{tag}/y", y)
+            put(out, f"{tag}/mask_out", mo)
+            put(out, f"{tag}/dx", x.grad)
+            put(out, f"{tag}/dw", layer.input_conv.weight.grad)
+            put(out, f"{tag}/db", layer.input_conv.bias.grad)
+            put(out, f"{tag}/dgamma", layer.bn.weight.grad)
+            put(out, f"{tag}/dbeta", layer.bn.bias.grad)
+            put(out, f"{tag}/running_mean", layer.bn.running_mean)
+            put(out, f"{tag}/running_var", layer.bn.running_var)
+            layer.eval()
+            with torch.no_grad():
+                ye, _ = layer(x, m)
+            put(out, f"{tag}/y_eval", ye)
+    return out
+
+
+def gen_models(ref_gen, ref_disc):
+    """Whole-generator / discriminator forward+backward at small sizes, incl. an odd size that
+    exercises _pad_to_match (generator.py:78-84)."""
+    out = {}
+    for tag, b, h, w in [("g64", 2, 64, 64), ("g72x40", 2, 72, 40), ("g96", 3, 96, 96)]:
+        torch.manual_seed(7)
+        G = ref_gen.PConvUNet()
+        x, m = synth_batch(b, max(h, w), 300 + h)
+        x, m = x[:, :, :h, :w].contiguous(), m[:, :, :h, :w].contiguous()
+        xm = (x * m).requires_grad_(True)
+        y = G(xm, m)
+        g = torch.Generator().manual_seed(5)
+        gy = torch.randn(y.shape, generator=g)
+        (y * gy).sum().backward()
+        out[f"{tag}/cfg"] = np.array([b, h, w], dtype=np.int64)
+        put(out, f"{tag}/out", y)
+        put(out, f"{tag}/dx", xm.grad)
+        for n, p_ in G.named_parameters():
+            if p_.grad is not None:
+                put(out, f"{tag}/grad/{n}", p_.grad, full_limit=2048)
+        for n, buf in G.named_buffers():
+            if "running" in n:
+                put(out, f"{tag}/buf/{n}", buf, full_limit=2048)
+        G.eval()
+        with torch.no_grad():
+            put(out, f"{tag}/out_eval", G(xm.detach(), m))
+    for tag, b, h, w in [("d64", 2, 64, 64), ("d80x48", 3, 80, 48)]:
+        torch.manual_seed(8)
+        D = ref_disc.Discriminator()
+        g = torch.Generator().manual_seed(6)
+        x = torch.rand(b, 1, h, w, generator=g, requires_grad=True)
+        y = D(x)
+        gy = torch.randn(y.shape, generator=g)
+        (y * gy).sum().backward()
+        out[f"{tag}/cfg"] = np.array([b, h, w], dtype=np.int64)
+        put(out, f"{tag}/out", y)
+        put(out, f"{tag}/dx", x.grad)
+        for n, p_ in D.named_parameters():
+            put(out, f"{tag}/grad/{n}", p_.grad, full_limit=2048)
+        for n, buf in D.named_buffers():
+            if "running" in n:
+                put(out, f"{tag}/buf/{n}", buf, full_limit=2048)
+    return out
+
+
+def gen_losses(ref_losses):
+    out = {}
+    torch.manual_seed(11)
+    crit = ref_losses.InpaintingLoss(0.1, 0.1, device=torch.device("cpu"))
+    g = torch.Generator().manual_seed(12)
+    for tag, b, h, w, kind in [("l32", 2, 32, 32, "blocks"), ("l32ones", 2, 32, 32, "ones"),
+                               ("l48x40", 3, 48, 40, "holes30"), ("l32zeros", 1, 32, 32, "zeros")]:
+        pred = torch.rand(b, 1, h, w, generator=g, requires_grad=True)
+        tgt = torch.rand(b, 1, h, w, generator=g)
+        m = mask_case(kind, b, h, w, g)
+        out[f"{tag}/cfg"] = np.array([b, h, w], dtype=np.int64)
+        out[f"{tag}/pred"] = pred.detach().numpy()
+        out[f"{tag}/target"] = tgt.numpy()
+        out[f"{tag}/mask"] = m.numpy().astype(np.uint8)
+        total = crit(pred, tgt, m)
+        total.backward()
+        put(out, f"{tag}/total", total)
+        put(out, f"{tag}/dpred", pred.grad)
+        with torch.no_grad():
+            put(out, f"{tag}/l1", crit.l1_loss(pred, tgt))
+            put(out, f"{tag}/tv", crit.total_variation_loss(pred * (1 - m)))
+            put(out, f"{tag}/boundary", crit.boundary_loss(pred, tgt, m))
+            put(out, f"{tag}/perc", crit.l1_loss(crit.vgg_layers(pred.repeat(1, 3, 1, 1)),
+                                                 crit.vgg_layers(tgt.repeat(1, 3, 1, 1))))
+    # human-guided loss (losses.py:132-204)
+    cfg = {"training": {"loss_weights": {"boundary": 0.5},
+                        "modes": {"human_guided": {"human_feedback_weight": 0.3, "base_loss_weight": 0.7}}}}
+    torch.manual_seed(11)
+    hcrit = ref_losses.HumanGuidedLoss(cfg, device=torch.device("cpu"))
+    pred = torch.rand(2, 1, 32, 32, generator=g, requires_grad=True)
+    tgt = torch.rand(2, 1, 32, 32, generator=g)
+    m = mask_case("blocks", 2, 32, 32, g)
+    hm = mask_case("blocks", 2, 32, 32, g) * 255.0
+    out["hg/pred"], out["hg/target"] = pred.detach().numpy(), tgt.numpy()
+    out["hg/mask"], out["hg/human"] = m.numpy().astype(np.uint8), hm.numpy().astype(np.uint8)
+    tot = hcrit(pred, tgt, m, {"mask": hm})
+    tot.backward()
+    put(out, "hg/total", tot)
+    put(out, "hg/dpred", pred.grad)
+    # BCE-with-logits, constant targets (train.py:115,203,215-216)
+    bce = nn.BCEWithLogitsLoss()
+    z = (torch.randn(2, 1, 15, 15, generator=g) * 3).requires_grad_(True)
+    out["bce/logits"] = z.detach().numpy()
+    for tv_, nm in [(1.0, "one"), (0.0, "zero")]:
+        z.grad = None
+        l_ = bce(z, torch.full_like(z, tv_))
+        l_.backward()
+        put(out, f"bce/{nm}", l_)
+        put(out, f"bce/d{nm}", z.grad)
+    return out
+
+
+def _ref_step(G, D, crit, bce, oG, oD, real, mask):
+    """The reference loop body, train.py:177-219, driven verbatim in order."""
+    masked = real * mask
+    oG.zero_grad()
+    gen = G(masked, mask)
+    g_loss = crit(gen, real, mask)
+    fv = D(gen)
+    g_adv = bce(fv, torch.ones_like(fv))
+    g_total = g_loss + g_adv
+    g_total.backward()
+    ggrads = {n: p.grad.clone() for n, p in G.named_parameters() if p.grad is not None}
+    oG.step()
+    oD.zero_grad()
+    rv = D(real)
+    fv = D(gen.detach())
+    real_loss = bce(rv, torch.ones_like(rv))
+    fake_loss = bce(fv, torch.zeros_like(fv))
+    d_loss = 0.5 * (real_loss + fake_loss)
+    d_loss.backward()
+    dgrads = {n: p.grad.clone() for n, p in D.named_parameters() if p.grad is not None}
+    oD.step()
+    sc = dict(g_total=g_total, g_loss=g_loss, g_adv=g_adv, d_loss=d_loss, real_loss=real_loss,
+              fake_loss=fake_loss)
+    return gen.detach(), {k: float(v) for k, v in sc.items()}, ggrads, dgrads
+
+
+def _build(ref_gen, ref_disc, ref_losses, seed=0):
+    torch.manual_seed(seed)
+    G, D = ref_gen.PConvUNet(), ref_disc.Discriminator()
+    crit = ref_losses.InpaintingLoss(0.1, 0.1, device=torch.device("cpu"))
+    oG = torch.optim.Adam(G.parameters(), lr=2e-4)
+    oD = torch.optim.Adam(D.parameters(), lr=2e-4)
+    return G, D, crit, oG, oD
+
+
+def gen_steps(ref_gen, ref_disc, ref_losses):
+    out = {}
+    bce = nn.BCEWithLogitsLoss()
+    for tag, b, size, nsteps, seed0 in [("c1_256", 1, 256, 3, 1), ("b2_64", 2, 64, 3, 40)]:
+        G, D, crit, oG, oD = _build(ref_gen, ref_disc, ref_losses)
+        G.train(), D.train()
+        out[f"{tag}/cfg"] = np.array([b, size, nsteps, seed0], dtype=np.int64)
+        for s in range(nsteps):
+            real, mask = synth_batch(b, size, seed0 + s)
+            gen, sc, gg, dg = _ref_step(G, D, crit, bce, oG, oD, real, mask)
+            for k, v in sc.items():
+                out[f"{tag}/s{s}/{k}"] = np.float64(v)
+            put(out, f"{tag}/s{s}/gen", gen, full_limit=70000)
+            if s == 0:
+                for n, t in gg.items():
+                    put(out, f"{tag}/s0/ggrad/{n}", t, full_limit=64)
+                for n, t in dg.items():
+                    put(out, f"{tag}/s0/dgrad/{n}", t, full_limit=64)
+            if s in (0, nsteps - 1):
+                for n, p_ in list(G.named_parameters()) + list(D.named_parameters()):
+                    pre = "G" if any(p_ is q for q in G.parameters()) else "D"
+                    out[f"{tag}/s{s}/w/{pre}.{n}"] = np.array(
+                        [float(p_.double().sum()), float(p_.double().abs().sum())])
+                for n, buf in list(G.named_buffers()) + list(D.named_buffers()):
+                    if "running" in n and n.split(".")[0] in ("enc1", "enc7", "dec1", "model"):
+                        put(out, f"{tag}/s{s}/buf/{n}", buf, full_limit=1024)
+    # data-parallel emulation: N micro-batches, identical weights, mean grads, one Adam
+    import copy
+    for tag, n, b, size in [("dp2_64", 2, 2, 64)]:
+        G, D, crit, oG, oD = _build(ref_gen, ref_disc, ref_losses)
+        out[f"{tag}/cfg"] = np.array([n, b, size], dtype=np.int64)
+        gens, gsum = [], {}
+        reps = [(G, D)] + [(copy.deepcopy(G), copy.deepcopy(D)) for _ in range(n - 1)]
+        batches = [synth_batch(b, size, 1000 + r) for r in range(n)]
+        for r, (Gr, Dr) in enumerate(reps):
+            Gr.train(), Dr.train()
+            real, mask = batches[r]
+            Gr.zero_grad()
+            gen = Gr(real * mask, mask)
+            fv = Dr(gen)
+            tot = crit(gen, real, mask) + bce(fv, torch.ones_like(fv))
+            tot.backward()
+            out[f"{tag}/r{r}/g_total"] = np.float64(float(tot))
+            gens.append(gen.detach())
+            for (nm, p_) in Gr.named_parameters():
+                if p_.grad is not None:
+                    gsum[nm] = gsum.get(nm, 0) + p_.grad / n
+        for nm, p_ in G.named_parameters():
+            if nm in gsum:
+                p_.grad = gsum[nm].clone()
+        oG.step()
+        dsum = {}
+        for r, (Gr, Dr) in enumerate(reps):
+            real, mask = batches[r]
+            Dr.zero_grad()
+            rv, fv = Dr(real), Dr(gens[r])
+            dl = 0.5 * (bce(rv, torch.ones_like(rv)) + bce(fv, torch.zeros_like(fv)))
+            dl.backward()
+            out[f"{tag}/r{r}/d_loss"] = np.float64(float(dl))
+            for (nm, p_) in Dr.named_parameters():
+                dsum[nm] = dsum.get(nm, 0) + p_.grad / n
+        for nm, p_ in D.named_parameters():
+            p_.grad = dsum[nm].clone()
+        oD.step()
+        for nm, t in gsum.items():
+            put(out, f"{tag}/ggrad/{nm}", t, full_limit=64)
+        for nm, t in dsum.items():
+            put(out, f"{tag}/dgrad/{nm}", t, full_limit=64)
+        for nm, p_ in G.named_parameters():
+            out[f"{tag}/w/G.{nm}"] = np.array([float(p_.double().sum()), float(p_.double().abs().sum())])
+        for nm, p_ in D.named_parameters():
+            out[f"{tag}/w/D.{nm}"] = np.array([float(p_.double().sum()), float(p_.double().abs().sum())])
+    return out
+
+
+def gen_init(ref_gen, ref_disc, ref_losses):
+    """Seeded-init parity + state-dict key contract (SURVEY §5 'Checkpoint', §8b)."""
+    out = {}
+    G, D, crit, _, _ = _build(ref_gen, ref_disc, ref_losses)
+    for pre, mod in [("G", G), ("D", D), ("V", crit.vgg_layers)]:
+        sd = mod.state_dict()
+        out[f"{pre}/keys"] = np.array(list(sd.keys()))
+        out[f"{pre}/shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        for k, v in sd.items():
+            if v.dtype.is_floating_point:
+                out[f"{pre}/w/{k}"] = np.array([float(v.double().sum()), float(v.double().abs().sum())])
+                out[f"{pre}/first/{k}"] = v.flatten()[:8].numpy()
+    return out
+
+
+def main():
+    ref_pconv, ref_gen, ref_disc, ref_losses = _load_reference()
+    jobs = {
+        "pconv_layers": lambda: gen_pconv(ref_pconv),
+        "models": lambda: gen_models(ref_gen, ref_disc),
+        "losses": lambda: gen_losses(ref_losses),
+        "init": lambda: gen_init(ref_gen, ref_disc, ref_losses),
+        "steps": lambda: gen_steps(ref_gen, ref_disc, ref_losses),
+    }
+    only = sys.argv[1:]
+    for name, fn in jobs.items():
+        if only and name not in only:
+            continue
+        data = fn()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **data)
+        print(f"{name}: {len(data)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+"""Pin the CPU oracle against fixtures generated from the reference itself (CPU only).
+
+Tolerances are the calibrated fp32 ones of SURVEY.md §8c: outputs atol 2e-6, loss scalars rtol
+1e-6 (a little slack for summation order), gradients max|d| <= 1e-3*max|g| + 1e-6.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import terragan_oracle as O
+from tests import golden_util as GU
+
+torch.set_num_threads(8)
+
+
+@pytest.mark.parametrize("ci", range(len(GU.PCONV_CASES)))
+def test_pconv_layer(ci):
+    gold = GU.load("pconv_layers")
+    cin, cout, k, s, p, b, h, w = GU.PCONV_CASES[ci]
+    for kind in GU.MASK_KINDS:
+        tag = f"c{ci}_{kind}"
+        torch.manual_seed(100 + ci)
+        prm = {}
+        O.init_pconv(prm, "L", cin, cout, k)
+        prm["L.bn.weight"].uniform_(0.5, 1.5)
+        prm["L.bn.bias"].uniform_(-0.3, 0.3)
+        g = torch.Generator().manual_seed(200 + ci)
+        x = torch.randn(b, cin, h, w, generator=g, requires_grad=True)
+        m = GU.mask_case(kind, b, h, w, g)
+        keys = ["L.input_conv.weight", "L.input_conv.bias", "L.bn.weight", "L.bn.bias"]
+        for kk in keys:
+            prm[kk].requires_grad_(True)
+        y, mo = O.pconv(x, m, prm, "L", True, spec=(cin, cout, k, s, p))
+        gy = torch.randn(y.shape, generator=g)
+        grads = torch.autograd.grad((y * gy).sum(), [x] + [prm[kk] for kk in keys])
+        GU.check(gold, f"{tag}/y", y, atol=1e-5, rtol=1e-5)
+        GU.check(gold, f"{tag}/mask_out", mo, atol=0, rtol=0)
+        for nm, gr in zip(["dx", "dw", "db", "dgamma", "dbeta"], grads):
+            GU.check(gold, f"{tag}/{nm}", gr, atol=1e-5, rtol=1e-3, scale_by_max=True)
+        GU.check(gold, f"{tag}/running_mean", prm["L.bn.running_mean"], atol=1e-6)
+        GU.check(gold, f"{tag}/running_var", prm["L.bn.running_var"], atol=1e-6)
+        with torch.no_grad():
+            ye, _ = O.pconv(x, m, prm, "L", False, spec=(cin, cout, k, s, p))
+        GU.check(gold, f"{tag}/y_eval", ye, atol=1e-5, rtol=1e-5)
+
+
+def test_seeded_init_and_keys():
+    gold = GU.load("init")
+    st = O.TrainState(0)
+    for pre, prm in [("G", st.gp), ("D", st.dp), ("V", st.vp)]:
+        assert list(prm.keys()) == [str(k) for k in gold[f"{pre}/keys"]], pre
+        shapes = [",".join(map(str, v.shape)) for v in prm.values()]
+        assert shapes == [str(s) for s in gold[f"{pre}/shapes"]]
+        for k, v in prm.items():
+            if v.dtype.is_floating_point:
+                assert np.array_equal(v.flatten()[:8].numpy(), gold[f"{pre}/first/{k}"]), k
+                ref = gold[f"{pre}/w/{k}"]
+                assert float(v.double().sum()) == ref[0] and float(v.double().abs().sum()) == ref[1], k
+    assert len(st.gp) == 114 and len(st.dp) == 25      # SURVEY §5 checkpoint contract
+
+
+@pytest.mark.parametrize("tag", ["g64", "g72x40", "g96"])
+def test_generator(tag):
+    gold = GU.load("models")
+    b, h, w = [int(v) for v in gold[f"{tag}/cfg"]]
+    torch.manual_seed(7)
+    gp = O.init_generator()
+    x, m = O.synth_batch(b, max(h, w), 300 + h)
+    x, m = x[:, :, :h, :w].contiguous(), m[:, :, :h, :w].contiguous()
+    xm = (x * m).requires_grad_(True)
+    keys = O.trainable(gp)
+    for k in keys:
+        gp[k].requires_grad_(True)
+    y = O.generator_forward(gp, xm, m, True)
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5))
+    grads = torch.autograd.grad((y * gy).sum(), [xm] + [gp[k] for k in keys])
+    GU.check(gold, f"{tag}/out", y, atol=2e-6)
+    GU.check(gold, f"{tag}/dx", grads[0], atol=1e-6, rtol=1e-3, scale_by_max=True)
+    for k, gr in zip(keys, grads[1:]):
+        GU.check(gold, f"{tag}/grad/{k}", gr, atol=1e-6, rtol=1e-3, scale_by_max=True)
+    for k in gp:
+        if "running" in k:
+            GU.check(gold, f"{tag}/buf/{k}", gp[k], atol=1e-6, rtol=1e-5)
+    with torch.no_grad():
+        GU.check(gold, f"{tag}/out_eval", O.generator_forward(gp, xm.detach(), m, False), atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["d64", "d80x48"])
+def test_discriminator(tag):
+    gold = GU.load("models")
+    b, h, w = [int(v) for v in gold[f"{tag}/cfg"]]
+    torch.manual_seed(8)
+    dp = O.init_discriminator()
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(b, 1, h, w, generator=g, requires_grad=True)
+    keys = O.trainable(dp)
+    for k in keys:
+        dp[k].requires_grad_(True)
+    y = O.discriminator_forward(dp, x, True)
+    gy = torch.randn(y.shape, generator=g)
+    grads = torch.autograd.grad((y * gy).sum(), [x] + [dp[k] for k in keys])
+    GU.check(gold, f"{tag}/out", y, atol=1e-5, rtol=1e-5)
+    GU.check(gold, f"{tag}/dx", grads[0], atol=1e-6, rtol=1e-3, scale_by_max=True)
+    for k, gr in zip(keys, grads[1:]):
+        # conv biases feeding BN have analytically-zero gradients: absolute noise floor
+        GU.check(gold, f"{tag}/grad/{k}", gr, atol=2e-5, rtol=1e-3, scale_by_max=True)
+    for k in dp:
+        if "running" in k:
+            GU.check(gold, f"{tag}/buf/{k}", dp[k], atol=1e-6, rtol=1e-5)
+
+
+def test_losses():
+    gold = GU.load("losses")
+    torch.manual_seed(11)
+    vp = O.init_vgg_standin()
+    for tag in ["l32", "l32ones", "l48x40", "l32zeros"]:
+        pred = torch.from_numpy(gold[f"{tag}/pred"]).requires_grad_(True)
+        tgt = torch.from_numpy(gold[f"{tag}/target"])
+        m = torch.from_numpy(gold[f"{tag}/mask"]).float()
+        total, parts = O.inpainting_loss(vp, pred, tgt, m)
+        (dp,) = torch.autograd.grad(total, pred)
+        GU.check(gold, f"{tag}/total", total, atol=1e-7, rtol=2e-6)
+        GU.check(gold, f"{tag}/dpred", dp, atol=1e-9, rtol=1e-3, scale_by_max=True)
+        for nm in ["l1", "tv", "boundary", "perc"]:
+            GU.check(gold, f"{tag}/{nm}", parts[nm], atol=1e-7, rtol=2e-6)
+    pred = torch.from_numpy(gold["hg/pred"]).requires_grad_(True)
+    tot = O.human_guided_loss(vp, pred, torch.from_numpy(gold["hg/target"]),
+                              torch.from_numpy(gold["hg/mask"]).float(),
+                              torch.from_numpy(gold["hg/human"]).float())
+    (dp,) = torch.autograd.grad(tot, pred)
+    GU.check(gold, "hg/total", tot, atol=1e-7, rtol=2e-6)
+    GU.check(gold, "hg/dpred", dp, atol=1e-9, rtol=1e-3, scale_by_max=True)
+    z = torch.from_numpy(gold["bce/logits"]).requires_grad_(True)
+    for tv_, nm in [(1.0, "one"), (0.0, "zero")]:
+        l_ = O.bce_logits(z, tv_)
+        (dz,) = torch.autograd.grad(l_, z)
+        GU.check(gold, f"bce/{nm}", l_, atol=1e-7, rtol=1e-6)
+        GU.check(gold, f"bce/d{nm}", dz, atol=1e-9, rtol=1e-5)
+
+
+def _check_weights(gold, prefix, st, lr_steps):
+    for pre, prm in [("G", st.gp), ("D", st.dp)]:
+        for k in O.trainable(prm):
+            ref = gold[f"{prefix}/w/{pre}.{k}"]
+            n = prm[k].numel()
+            # |dw| <= 1e-3*lr*steps per element; analytically-zero-grad D biases lr*steps
+            per = lr_steps if (pre == "D" and k in ("model.2.bias", "model.5.bias", "model.8.bias")) \
+                else 1e-3 * lr_steps
+            tol = per * n + 1e-6 * abs(ref[1])
+            assert abs(float(prm[k].double().sum()) - ref[0]) <= tol, (prefix, pre, k)
+            assert abs(float(prm[k].double().abs().sum()) - ref[1]) <= tol, (prefix, pre, k)
+
+
+@pytest.mark.parametrize("tag", ["b2_64", "c1_256"])
+def test_train_steps(tag):
+    gold = GU.load("steps")
+    b, size, nsteps, seed0 = [int(v) for v in gold[f"{tag}/cfg"]]
+    st = O.TrainState(0)
+    for s in range(nsteps):
+        real, mask = O.synth_batch(b, size, seed0 + s)
+        gen, sc, gg, dg = O.train_step(st, real, mask)
+        # later steps inherit O(lr) weight differences from Adam's sign sensitivity
+        loosen = 1.0 if s == 0 else 50.0
+        for k in ["g_total", "g_loss", "g_adv", "d_loss", "real_loss", "fake_loss"]:
+            ref = float(gold[f"{tag}/s{s}/{k}"])
+            assert abs(float(sc[k]) - ref) <= loosen * 2e-6 * abs(ref) + 1e-7, (s, k, float(sc[k]), ref)
+        GU.check(gold, f"{tag}/s{s}/gen", gen, atol=2e-6 * loosen, rtol=0)
+        if s == 0:
+            for k, t in gg.items():
+                GU.check(gold, f"{tag}/s0/ggrad/{k}", t, atol=1e-6, rtol=1e-3, scale_by_max=True)
+            for k, t in dg.items():
+                GU.check(gold, f"{tag}/s0/dgrad/{k}", t, atol=2e-5, rtol=1e-3, scale_by_max=True)
+        if s in (0, nsteps - 1):
+            _check_weights(gold, f"{tag}/s{s}", st, 2e-4 * (s + 1))
+
+
+def test_dp_emulation():
+    gold = GU.load("steps")
+    n, b, size = [int(v) for v in gold["dp2_64/cfg"]]
+    st = O.TrainState(0)
+    batches = [O.synth_batch(b, size, 1000 + r) for r in range(n)]
+    gens, scal = O.dp_train_step(st, [x for x, _ in batches], [m for _, m in batches])
+    for r in range(n):
+        for k in ["g_total", "d_loss"]:
+            ref = float(gold[f"dp2_64/r{r}/{k}"])
+            assert abs(float(scal[r][k]) - ref) <= 2e-6 * abs(ref) + 1e-7, (r, k)
+    _check_weights(gold, "dp2_64", st, 2e-4)

@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- DSM tiles/sec through one full GAN train step (G + D + losses + Adam).
+
+Workload = BASELINE.json configs[1]: 256x256 1-channel synthetic DSM tiles + random disc masks, batch 16
+PER GPU, fp32, partial-conv U-Net generator + PatchGAN discriminator + L1/perceptual/TV/boundary losses.
+A "step" is one pass of mvp_gan.src.train.train_step over one batch that is already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = tiles processed by all ranks / max-over-ranks wall time of exactly K
+steps (barrier + synchronize on both sides).  `roofline` is measured live: an extra instrumented pass after the
+timed region brackets every launch of the dominant kernel (the fp32-MFMA implicit-GEMM conv) with hipEvents on
+its launch stream (tg_prof_*), achieved = sum of algorithmic FLOPs / sum of kernel time.  `cpu_baseline` times
+the CPU oracle (oracle/terragan_oracle.py, "port") on the host cores, rank 0 at N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "terra-gan_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+TILE = 256
+BATCH = 16
+
+
+def prof_summary(lib, kind):
+    ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+    lib.tg_prof_summary(kind, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
+    return ms.value, n.value, fl.value, by.value
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """CPU oracle train step on the host cores: bounded sample of the same workload (batch 4, 256x256)."""
+    from oracle import terragan_oracle as Orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    st = Orc.TrainState(0)
+    b = 4
+    real, mask = Orc.synth_batch(b, TILE, 1000)
+    Orc.train_step(st, real, mask)                      # warm-up (oneDNN primitive creation)
+    t0, n = time.perf_counter(), 0
+    while True:
+        Orc.train_step(st, real, mask)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget * 0.5 or n >= 4:
+            break
+    return {"value": round(b * n / el, 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} train steps of the CPU oracle at batch {b}, 256x256 fp32, after 1 warm-up step ({el:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (default: BASELINE config 2)")
+    ap.add_argument("--size", type=int, default=TILE)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+
+    from mvp_gan.src.models import Discriminator, PConvUNet
+    from mvp_gan.src.train import train_step
+    from mvp_gan.src.utils.losses import InpaintingLoss
+    from oracle.terragan_oracle import synth_batch       # input recipe only
+    from tg_hip import lib as L
+    from tg_hip.dist import GradSync
+    lib = L.load()
+
+    torch.manual_seed(0)                                    # identical weights on every rank
+    G, D = PConvUNet(), Discriminator()
+    crit = InpaintingLoss(0.1, 0.1, device=torch.device("cpu"))
+    G, D, crit = G.to(dev), D.to(dev), crit.to(dev)
+    oG = torch.optim.Adam(G.parameters(), lr=2e-4)
+    oD = torch.optim.Adam(D.parameters(), lr=2e-4)
+    G.train(), D.train()
+    sync = GradSync(world) if world > 1 else None
+
+    nb = 4                                                  # distinct resident batches, cycled
+    batches = []
+    for i in range(nb):
+        real, mask = synth_batch(args.batch, args.size, 1000 + i * world + rank)
+        batches.append((real.to(dev), mask.to(dev)))
+
+    def run(k):
+        for i in range(k):
+            real, mask = batches[i % nb]
+            train_step(G, D, crit, oG, oD, real, mask, grad_sync=sync)
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # instrumented pass (outside the timed region): hipEvents around every MFMA conv launch
+        lib.tg_prof_enable(1)
+        run(2)
+        torch.cuda.synchronize()
+        lib.tg_prof_enable(0)
+        ms0, n0, fl0, by0 = prof_summary(lib, 0)
+        ms1, n1, fl1, by1 = prof_summary(lib, 1)
+        ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "igemm_kernel (fp32 MFMA implicit-GEMM conv fwd/dgrad)",
+                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": n0 // 2, "avg_launch_ms": round(ms0 / max(n0, 1), 4),
+                    "gflop_per_launch": round(fl0 / max(n0, 1) / 1e9, 3), "kernel_ms_per_step": round(ms0 / 2, 3),
+                    "hbm_alg_GBps": round(by0 / (ms0 * 1e-3) / 1e9, 1) if ms0 > 0 else 0.0,
+                    "wgrad": {"achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else 0.0,
+                              "launches_per_step": n1 // 2, "kernel_ms_per_step": round(ms1 / 2, 3),
+                              "hbm_alg_GBps": round(by1 / (ms1 * 1e-3) / 1e9, 1) if ms1 > 0 else 0.0}}
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        tiles = args.batch * world * args.steps
+        line = {"metric": "DSM tiles/sec train-step (G+D) at 256x256 bs=16", "value": round(tiles / elapsed, 2),
+                "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"BASELINE configs[1]: {args.size}x{args.size} 1-ch DSM tiles, batch {args.batch} per GPU, "
+                                       "fp32, PConv-UNet G + PatchGAN D + L1/VGG-perceptual/TV/boundary losses + 2x Adam",
+                           "global_batch": args.batch * world, "tile": args.size,
+                           "parallelism": f"dp{world}" if world > 1 else "single-gpu",
+                           "vgg_weights": "deterministic stand-in (ImageNet weights not fetchable offline; same FLOPs)"},
+                "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,201 @@
+/*
+ * terragan_hip.h -- C ABI of libterragan_hip.so: the MI355X (gfx950) kernels behind TERRA-GAN's
+ * partial-convolution inpainting train step.
+ *
+ * The reference (/root/reference) is pure Python on stock ATen ops and has no native interface;
+ * each entry point below names the reference arithmetic it replaces (file:line) and is what a
+ * maintainer would bind (ctypes stub in INTEGRATION.md) from mvp_gan/src/models/{pconv,generator,discriminator}.py,
+ * mvp_gan/src/utils/losses.py and mvp_gan/src/train.py.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all pointers are DEVICE pointers (fp32 unless noted);
+ *   - activations are NHWC ("channels-last"): [B][H][W][C]; masks are [B][H][W] fp32 {0,1},
+ *     1 = valid pixel, 0 = hole (dataset.py:37, generator.py:60-62);
+ *   - conv weights are [Cout][kh][kw][Cin] (= the channels_last storage of an OIHW tensor);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never allocates,
+ *     never synchronises; scratch memory is supplied by the caller (`ws`, sized by the matching
+ *     tg_*_ws_bytes query);
+ *   - return 0 on success, negative TG_ERR_* otherwise; tg_last_error() gives the thread-local
+ *     message.  Invalid shapes are rejected on the host before any launch.
+ */
+#ifndef TERRAGAN_HIP_H
+#define TERRAGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tg_stream_t; /* hipStream_t */
+
+enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_LAUNCH = -2, TG_ERR_WS = -3 };
+enum { TG_ACT_NONE = 0, TG_ACT_RELU = 1, TG_ACT_LEAKY = 2 };
+
+/* Geometry of one 2-D convolution (square kernel, symmetric padding). */
+typedef struct TgConv {
+    int32_t B, H, W, Cin;   /* input  [B][H][W][Cin]   */
+    int32_t Ho, Wo, Cout;   /* output [B][Ho][Wo][Cout] */
+    int32_t k, stride, pad;
+} TgConv;
+
+int tg_version(void);
+const char* tg_last_error(void);
+
+/* ---- partial / plain convolution: implicit-GEMM on fp32 MFMA ------------------------------- */
+
+/* y = act( (conv(x (.) in_mask, w) + bias) * ratio )
+ * Replaces PConv2d.forward's input*mask -> input_conv -> output*mask_ratio (pconv.py:27-30,43)
+ * when in_mask/ratio are given, and nn.Conv2d (+LeakyReLU/ReLU) otherwise
+ * (generator.py:29,56; discriminator.py:11,15,22; losses.py:32 VGG trunk).
+ * in_mask [B][H][W], bias [Cout], ratio [B][Ho][Wo] may be NULL. */
+size_t tg_conv_fwd_ws_bytes(const TgConv* g);
+int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask, const float* w,
+                const float* bias, const float* ratio, int act, float slope, float* y,
+                float* ws, size_t ws_bytes, tg_stream_t stream);
+
+/* dx (+)= conv_transpose(dy, w) (.) in_mask   -- autograd of the conv above w.r.t. x.
+ * dy must already carry the ratio factor.  accumulate!=0 adds into dx (skip connections).
+ * ws >= tg_conv_dgrad_ws_bytes (holds the [Cin][kh][kw][Cout] transposed weights + split-K). */
+size_t tg_conv_dgrad_ws_bytes(const TgConv* g);
+int tg_conv_dgrad(const TgConv* g, const float* dy, const float* w, const float* in_mask,
+                  float* dx, int accumulate, float* ws, size_t ws_bytes, tg_stream_t stream);
+
+/* dw[Cout][k][k][Cin] = sum_pixels dy (x) (x (.) in_mask);  db[Cout] = sum_pixels dy (db may be NULL).
+ * Deterministic: split-K partial slabs in ws, reduced in a fixed order. */
+size_t tg_conv_wgrad_ws_bytes(const TgConv* g);
+int tg_conv_wgrad(const TgConv* g, const float* x, const float* in_mask, const float* dy,
+                  float* dw, float* db, float* ws, size_t ws_bytes, tg_stream_t stream);
+
+/* w3 [Cout][k][k][Cin] -> w1 [Cout][k][k][1] = sum over Cin: the VGG first conv sees the grey
+ * image repeated x3 (losses.py:79-80), i.e. a 1-channel conv with the channel-summed kernel. */
+int tg_fold_cin(const float* w3, int cout, int taps, int cin, float* w1, tg_stream_t stream);
+
+/* ---- mask path (exact integer arithmetic in fp32 storage) ---------------------------------- */
+
+/* S = window sum of mask; mask_out = [S>0]; ratio = k*k/(S+1e-8)*[S>0]   (pconv.py:33-40). */
+int tg_mask_update(const float* mask, int B, int H, int W, int k, int stride, int pad, int Ho,
+                   int Wo, float* mask_out, float* ratio, tg_stream_t stream);
+/* out = max(nearest_up2(up_mask) zero-padded to [H][W], skip_mask)  (generator.py:51-54,68-74). */
+int tg_mask_up_merge(const float* up_mask, const float* skip_mask, int B, int h, int w, int H,
+                     int W, float* out, tg_stream_t stream);
+
+/* ---- BatchNorm (+ReLU / LeakyReLU) ---------------------------------------------------------- */
+
+/* Training-mode batch statistics of y[rows][C] (biased var, eps inside rstd) and the running
+ * update with `momentum` (unbiased var) -- nn.BatchNorm2d, pconv.py:21,47; discriminator.py:13.
+ * running_* and num_batches_tracked (int64) may be NULL.  ws >= tg_bn_ws_bytes(rows, C). */
+size_t tg_bn_ws_bytes(int64_t rows, int C);
+int tg_bn_stats(const float* y, int64_t rows, int C, float eps, float momentum, float* save_mean,
+                float* save_rstd, float* running_mean, float* running_var,
+                int64_t* num_batches_tracked, float* ws, size_t ws_bytes, tg_stream_t stream);
+/* eval mode: mean = running_mean, rstd = 1/sqrt(running_var + eps). */
+int tg_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps,
+                     float* mean, float* rstd, tg_stream_t stream);
+/* out = act( (y-mean)*rstd*gamma + beta )   (pconv.py:47-48; discriminator.py:13-14). */
+int tg_bn_act_fwd(const float* y, int64_t rows, int C, const float* mean, const float* rstd,
+                  const float* gamma, const float* beta, int act, float slope, float* out,
+                  tg_stream_t stream);
+/* Backward of bn_act_fwd in training mode.  dy = dBN(dout (.) act'(.)) [* ratio[row]], dgamma,
+ * dbeta.  ratio may be NULL.  dy may alias dout. */
+int tg_bn_act_bwd(const float* dout, const float* y, int64_t rows, int C, const float* mean,
+                  const float* rstd, const float* gamma, const float* beta, int act, float slope,
+                  const float* ratio, float* dy, float* dgamma, float* dbeta, float* ws,
+                  size_t ws_bytes, tg_stream_t stream);
+/* din = dout * act'(out) [* ratio[row]] for a conv epilogue activation (out = post-activation).
+ * din may alias dout. */
+int tg_act_bwd(const float* dout, const float* out, int64_t rows, int C, int act, float slope,
+               const float* ratio, float* din, tg_stream_t stream);
+
+/* ---- decoder plumbing: bilinear x2 upsample (+) channel concat ------------------------------- */
+
+/* out[B][H][W][Cu+Cs] = cat( pad(bilinear_up2(up[B][h][w][Cu])), skip[B][H][W][Cs] )
+ * (generator.py:50,52,67,70,73; align_corners=False; skip may be NULL with Cs=0). */
+int tg_upcat_fwd(const float* up, const float* skip, int B, int h, int w, int Cu, int H, int W,
+                 int Cs, float* out, tg_stream_t stream);
+/* adjoint: dup[B][h][w][Cu] = bilinear_up2^T(dout[..., :Cu]);  dskip = dout[..., Cu:]. */
+int tg_upcat_bwd(const float* dout, int B, int h, int w, int Cu, int H, int W, int Cs, float* dup,
+                 float* dskip, tg_stream_t stream);
+
+/* ---- generator head --------------------------------------------------------------------------- */
+
+/* out = sigmoid(logits)*(1-mask) + x*mask   (generator.py:57-62), n = B*H*W. */
+int tg_sigmoid_composite_fwd(const float* logits, const float* x, const float* mask, int64_t n,
+                             float* out, tg_stream_t stream);
+/* dlogits = dout*(1-mask)*s*(1-s);  dx (may be NULL) = dout*mask. */
+int tg_sigmoid_composite_bwd(const float* dout, const float* logits, const float* mask, int64_t n,
+                             float* dlogits, float* dx, tg_stream_t stream);
+
+/* ---- VGG trunk helpers (losses.py:31-34,79-90) ------------------------------------------------ */
+int tg_maxpool2_fwd(const float* x, int B, int H, int W, int C, float* out, tg_stream_t stream);
+int tg_maxpool2_bwd(const float* dout, const float* x, int B, int H, int W, int C, float* dx,
+                    tg_stream_t stream);
+
+/* ---- losses ------------------------------------------------------------------------------------ */
+
+/* Pixel-space part of InpaintingLoss.forward (losses.py:73,98-100,118-127,404-416) in one pass
+ * family over (pred, target, mask) [B][H][W]:
+ *   out[0] = L1 mean, out[1] = TV(pred*(1-mask)) (B divided twice, as the reference),
+ *   out[2] = boundary loss (3x3 morphological-gradient band; 0 if the band is empty or the value
+ *            is NaN/Inf), out[3] = sum(band), out[4] = l1 + w_tv*tv + w_bnd*boundary.
+ * l1_weight (NULL = 1) weights |pred-target| inside the L1 mean: HumanGuidedLoss's human term
+ * L1(pred*h, target*h) with h in {0,1} (losses.py:173-176).
+ * If dpred != NULL also writes d out[4] / d pred * (*gscale) (gscale NULL = 1), accumulating into
+ * dpred when accumulate != 0.  No host synchronisation.  ws >= tg_pixel_loss_ws_bytes(). */
+size_t tg_pixel_loss_ws_bytes(int B, int H, int W);
+int tg_pixel_losses(const float* pred, const float* target, const float* mask,
+                    const float* l1_weight, int B, int H, int W,
+                    float w_l1, float w_tv, float w_bnd, float bnd_eps, const float* gscale,
+                    float* out5, float* dpred, int accumulate, float* ws, size_t ws_bytes,
+                    tg_stream_t stream);
+
+/* out[0] = mean |a-b| over n;  if da != NULL: da = coef * (*gscale) * sign(a-b)/n
+ * (nn.L1Loss on VGG features, losses.py:86-89). */
+size_t tg_reduce_ws_bytes(int64_t n);
+int tg_l1_mean(const float* a, const float* b, int64_t n, float coef, const float* gscale,
+               float* out1, float* da, float* ws, size_t ws_bytes, tg_stream_t stream);
+
+/* nn.BCEWithLogitsLoss (mean) against the constant `target` (train.py:115,203,215-216):
+ * out[0] = loss; if dz != NULL: dz = coef * (*gscale) * (sigmoid(z)-target)/n. */
+int tg_bce_logits(const float* z, int64_t n, float target, float coef, const float* gscale,
+                  float* out1, float* dz, float* ws, size_t ws_bytes, tg_stream_t stream);
+
+/* ---- optimiser / misc ---------------------------------------------------------------------------- */
+
+/* torch.optim.Adam defaults (main_pipeline.py:214-221; train.py:139-147): in-place update of
+ * p, m (exp_avg), v (exp_avg_sq) from g*grad_scale with bias correction for `step` (1-based). */
+int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+            float beta2, float eps, int step, float grad_scale, tg_stream_t stream);
+
+/* y = a*x + b*y elementwise (gradient accumulation / scaling glue). */
+int tg_axpby(const float* x, float a, float b, float* y, int64_t n, tg_stream_t stream);
+/* out = a*x + b*y of two device scalars/vectors into a third (loss totals). */
+int tg_lincomb(const float* x, float a, const float* y, float b, float* out, int64_t n,
+               tg_stream_t stream);
+/* out = a*b elementwise (masked_imgs = real_imgs * masks, train.py:181). */
+int tg_mul(const float* a, const float* b, float* out, int64_t n, tg_stream_t stream);
+/* Re-apply the BatchNorm running-stat momentum update from saved batch statistics
+ * (mean, rstd as written by tg_bn_stats): used when a forward pass is provably identical to one
+ * already computed (D(gen) and D(gen.detach()), train.py:202,212) and only its running-stat side
+ * effect remains to be reproduced. */
+int tg_bn_running_update(const float* save_mean, const float* save_rstd, int64_t rows, int C,
+                         float eps, float momentum, float* running_mean, float* running_var,
+                         int64_t* num_batches_tracked, tg_stream_t stream);
+/* [B][C][H][W] <-> [B][H][W][C] transposes (API boundary only; C==1 tensors need none). */
+int tg_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, tg_stream_t stream);
+int tg_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, tg_stream_t stream);
+
+/* ---- measurement hooks (bench.py roofline figures; no reference counterpart) ------------------- */
+
+/* When enabled, every launch of the MFMA conv kernels is bracketed by hipEvents on its own launch
+ * stream and tagged with its algorithmic FLOPs and bytes.  kind: 0 = fwd/dgrad implicit GEMM,
+ * 1 = wgrad.  tg_prof_summary synchronises those events (host-blocking: call it outside any timed
+ * region), returns the totals for `kind` and consumes its records. */
+int tg_prof_enable(int on);
+int tg_prof_summary(int kind, double* total_ms, int64_t* launches, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TERRAGAN_HIP_H */

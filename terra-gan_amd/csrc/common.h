@@ -1,0 +1,58 @@
+// Shared host/device helpers for libterragan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "terragan_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void tg_set_error(const char* fmt, ...);
+
+#define TG_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            tg_set_error(__VA_ARGS__);   \
+            return TG_ERR_ARG;           \
+        }                                \
+    } while (0)
+
+#define TG_CHECK_LAUNCH(name)                                                        \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            tg_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return TG_ERR_LAUNCH;                                                    \
+        }                                                                            \
+    } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Memory-bound kernels: cap the grid and grid-stride the rest (256 CUs x 8 blocks).
+static inline int ew_grid(int64_t work_items, int block) {
+    int64_t g = cdiv64(work_items, block);
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    if (act == TG_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == TG_ACT_LEAKY) return v > 0.f ? v : v * slope;
+    return v;
+}

@@ -1,0 +1,806 @@
+// Implicit-GEMM convolution family on fp32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+//   tg_conv_fwd    y  = act((conv(x (.) m, W) + b) * ratio)         pconv.py:27-30,43 / nn.Conv2d
+//   tg_conv_dgrad  dx = convT(dy, W) (.) m                            autograd of the above
+//   tg_conv_wgrad  dW = sum_pix dy (x) (x (.) m),  db = sum_pix dy
+//
+// Layout: activations NHWC, weights [Cout][kh][kw][Cin].  One 256-thread workgroup (4 waves of 64)
+// owns a BM x BN output tile; K is walked in 32-deep steps through double-buffered LDS; each wave
+// holds WM x WN accumulator tiles of 32x32 (16 VGPRs each).  LDS images are [row][k] with a 36-float
+// row pitch so that the ds_read_b128 operand fetch (4 consecutive k per lane) is bank-conflict free;
+// MFMA number e of a k-group consumes element e of that fetch on both operands, i.e. k = 8g+4h+e
+// for lane half h -- a permutation of the k order, which a sum over k does not care about.
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// optional per-launch timing of the MFMA kernels (bench.py's roofline figures): when enabled, every
+// igemm / wgrad main-kernel launch is bracketed by hipEvents ON THE LAUNCH STREAM and tagged with
+// its algorithmic FLOPs (2*M*N*K of the un-padded problem) and algorithmic bytes.
+// ------------------------------------------------------------------------------------------------
+struct ProfRec {
+    hipEvent_t a, b;
+    int kind;  // 0 = igemm (fwd/dgrad), 1 = wgrad
+    double flops, bytes;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+    bool on = false;
+    ProfRec r{};
+    hipStream_t s;
+    ProfScope(hipStream_t st, int kind, double flops, double bytes) : s(st) {
+        if (!g_prof_on) return;
+        on = true;
+        r.kind = kind; r.flops = flops; r.bytes = bytes;
+        (void)hipEventCreate(&r.a);
+        (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(r);
+    }
+};
+
+extern "C" int tg_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return TG_OK;
+}
+// Synchronises the recorded events (host-blocking; never called inside a timed region) and returns the
+// totals for `kind`; the records of that kind are consumed.
+extern "C" int tg_prof_summary(int kind, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double ms = 0, fl = 0, by = 0;
+    int64_t n = 0;
+    std::vector<ProfRec> keep;
+    for (auto& r : g_prof) {
+        if (r.kind != kind) { keep.push_back(r); continue; }
+        (void)hipEventSynchronize(r.b);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.a, r.b);
+        ms += t; fl += r.flops; by += r.bytes; ++n;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.swap(keep);
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    if (flops) *flops = fl;
+    if (bytes) *bytes = by;
+    return TG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / dgrad: gathered-row A operand, dense K-contiguous B operand
+// ------------------------------------------------------------------------------------------------
+struct IGemmParams {
+    const float* src;       // A source, NHWC [B][IH][IW][C]
+    const float* amask;     // optional [B][IH][IW]: A row scale at the SOURCE pixel (x (.) mask)
+    const float* wmat;      // B matrix [N][Kfull], K-contiguous, K index = tapidx*C + c
+    const float* bias;      // optional [N]
+    const float* rowscale;  // optional, indexed by DESTINATION pixel (ratio / dgrad mask)
+    float* dst;             // NHWC [B][DH][DW][N]
+    float* ws;              // split-K slabs [splits][M][N] when splits > 1
+    int B, IH, IW, C;
+    int OH, OW, N, M;       // output grid of this launch, M = B*OH*OW
+    int DH, DW, ds, dy0, dx0;           // grid point (oy,ox) -> dst pixel (oy*ds+dy0, ox*ds+dx0)
+    int TH, TW, ss, tstep, sy0, sx0;    // tap (ty,tx) -> src pixel (oy*ss+sy0+ty*tstep, ...)
+    int KW, kstep, ky0, kx0;            // tap (ty,tx) -> weight tap (ky0+ty*kstep)*KW + kx0+tx*kstep
+    int Kfull, Ktot;        // wmat row length; K elements walked by this launch (TH*TW*C)
+    int nchunks, T;         // ceil(C/32); number of 32-deep K steps
+    int splits, steps_per_split;
+    int act;
+    float slope;
+    int accumulate;
+};
+
+__device__ __forceinline__ size_t dst_pixel(const IGemmParams& p, int m) {
+    if (p.ds == 1 && p.OH == p.DH && p.OW == p.DW) return (size_t)m;
+    int ox = m % p.OW;
+    int t = m / p.OW;
+    int oy = t % p.OH;
+    int b = t / p.OH;
+    return ((size_t)b * p.DH + (oy * p.ds + p.dy0)) * p.DW + (ox * p.ds + p.dx0);
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, LDK = 36;
+    constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;  // [2][BN][LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kc = tid & 7, r0 = tid >> 3;
+
+    int rb[A_LOADS], ry[A_LOADS], rx[A_LOADS];
+    bool rv[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        int m = m0 + r0 + 32 * i;
+        rv[i] = m < p.M;
+        int mm = rv[i] ? m : 0;
+        int ox = mm % p.OW;
+        int t = mm / p.OW;
+        int oy = t % p.OH;
+        rb[i] = t / p.OH;
+        ry[i] = oy * p.ss + p.sy0;
+        rx[i] = ox * p.ss + p.sx0;
+    }
+
+    const int t_begin = blockIdx.z * p.steps_per_split;
+    const int t_end = min(p.T, t_begin + p.steps_per_split);
+
+    f32x4 ra[A_LOADS], rw[B_LOADS];
+
+    auto gload = [&](int t) {
+        if constexpr (!SCALAR) {
+            const int tap = t / p.nchunks;
+            const int c0 = (t - tap * p.nchunks) * 32 + 4 * kc;
+            const int ty = tap / p.TW, tx = tap - ty * p.TW;
+            const int dyy = ty * p.tstep, dxx = tx * p.tstep;
+            const int widx = ((p.ky0 + ty * p.kstep) * p.KW + (p.kx0 + tx * p.kstep)) * p.C + c0;
+            const bool cv = c0 < p.C;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) {
+                int iy = ry[i] + dyy, ix = rx[i] + dxx;
+                bool ok = rv[i] && cv && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ok) {
+                    size_t pix = ((size_t)rb[i] * p.IH + iy) * p.IW + ix;
+                    v = *reinterpret_cast<const f32x4*>(p.src + pix * p.C + c0);
+                    if (p.amask) v *= p.amask[pix];
+                }
+                ra[i] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < B_LOADS; ++j) {
+                int n = n0 + r0 + 32 * j;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < p.N && cv) v = *reinterpret_cast<const f32x4*>(p.wmat + (size_t)n * p.Kfull + widx);
+                rw[j] = v;
+            }
+        } else {
+            // any C (1, 3, ...): K index decoded per element
+            int tapv[4], cval[4], dyv[4], dxv[4], wv[4];
+            bool kv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int k = t * 32 + 4 * kc + e;
+                kv[e] = k < p.Ktot;
+                int kk = kv[e] ? k : 0;
+                tapv[e] = kk / p.C;
+                cval[e] = kk - tapv[e] * p.C;
+                int ty = tapv[e] / p.TW, tx = tapv[e] - ty * p.TW;
+                dyv[e] = ty * p.tstep;
+                dxv[e] = tx * p.tstep;
+                wv[e] = ((p.ky0 + ty * p.kstep) * p.KW + (p.kx0 + tx * p.kstep)) * p.C + cval[e];
+            }
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int iy = ry[i] + dyv[e], ix = rx[i] + dxv[e];
+                    bool ok = rv[i] && kv[e] && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+                    if (ok) {
+                        size_t pix = ((size_t)rb[i] * p.IH + iy) * p.IW + ix;
+                        float s = p.src[pix * p.C + cval[e]];
+                        if (p.amask) s *= p.amask[pix];
+                        v[e] = s;
+                    }
+                }
+                ra[i] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < B_LOADS; ++j) {
+                int n = n0 + r0 + 32 * j;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n < p.N && kv[e]) v[e] = p.wmat[(size_t)n * p.Kfull + wv[e]];
+                rw[j] = v;
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+        float* Ab = As + buf * BM * LDK;
+        float* Bb = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            *reinterpret_cast<f32x4*>(Ab + (r0 + 32 * i) * LDK + 4 * kc) = ra[i];
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j)
+            *reinterpret_cast<f32x4*>(Bb + (r0 + 32 * j) * LDK + 4 * kc) = rw[j];
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int arow = wm * WM * 32 + (lane & 31);
+    const int brow = wn * WN * 32 + (lane & 31);
+    const int ko = 4 * (lane >> 5);
+
+    if (t_begin < t_end) {
+        gload(t_begin);
+        sstore(0);
+        __syncthreads();
+        for (int t = t_begin; t < t_end; ++t) {
+            const int cur = (t - t_begin) & 1;
+            const bool more = (t + 1) < t_end;
+            if (more) gload(t + 1);
+            const float* Ab = As + cur * BM * LDK;
+            const float* Bb = Bs + cur * BN * LDK;
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                f32x4 a[WM], b[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+                    a[i] = *reinterpret_cast<const f32x4*>(Ab + (arow + 32 * i) * LDK + kg * 8 + ko);
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    b[j] = *reinterpret_cast<const f32x4*>(Bb + (brow + 32 * j) * LDK + kg * 8 + ko);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            }
+            if (more) sstore(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int m = m0 + (wm * WM + i) * 32 + row;
+            if (m >= p.M) continue;
+            if (p.splits > 1) {
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
+                    if (n < p.N) p.ws[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
+                }
+            } else {
+                const size_t pix = dst_pixel(p, m);
+                const float rs = p.rowscale ? p.rowscale[pix] : 1.f;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
+                    if (n < p.N) {
+                        float v = acc[i][j][r];
+                        if (p.bias) v += p.bias[n];
+                        v = apply_act(v * rs, p.act, p.slope);
+                        float* d = p.dst + pix * p.N + n;
+                        if (p.accumulate) v += *d;
+                        *d = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// split-K second pass: fixed-order sum over the slabs + the same epilogue.
+__global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IGemmParams p) {
+    const size_t total = (size_t)p.M * p.N;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int m = (int)(idx / p.N), n = (int)(idx - (size_t)m * p.N);
+        float v = 0.f;
+        for (int z = 0; z < p.splits; ++z) v += p.ws[(size_t)z * total + idx];
+        const size_t pix = dst_pixel(p, m);
+        if (p.bias) v += p.bias[n];
+        if (p.rowscale) v *= p.rowscale[pix];
+        v = apply_act(v, p.act, p.slope);
+        float* d = p.dst + pix * p.N + n;
+        if (p.accumulate) v += *d;
+        *d = v;
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR>
+static int launch_igemm_cfg(const IGemmParams& p, hipStream_t s) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * 36 * sizeof(float);
+    static bool attr_done = false;
+    auto kern = igemm_kernel<WAVES_M, WAVES_N, WM, WN, SCALAR>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            tg_set_error("igemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return TG_ERR_LAUNCH;
+        }
+        attr_done = true;
+    }
+    dim3 grid(cdiv(p.M, BM), cdiv(p.N, BN), p.splits);
+    {
+        // algorithmic bytes: source pixels touched once + row scale/mask + weights + output
+        const double by = 4.0 * ((double)p.B * p.IH * p.IW * p.C + (double)p.M + (double)p.N * p.Ktot + (double)p.M * p.N +
+                                 (p.amask ? (double)p.B * p.IH * p.IW : 0.0));
+        ProfScope ps(s, 0, 2.0 * p.M * (double)p.N * p.Ktot, by);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    }
+    TG_CHECK_LAUNCH("igemm_kernel");
+    if (p.splits > 1) {
+        hipLaunchKernelGGL(igemm_splitk_epilogue, dim3(ew_grid((int64_t)p.M * p.N, 256)), dim3(256), 0, s, p);
+        TG_CHECK_LAUNCH("igemm_splitk_epilogue");
+    }
+    return TG_OK;
+}
+
+static int pick_bn(int N) { return N >= 128 && N % 128 == 0 ? 128 : (N > 32 ? 64 : 32); }
+
+// K-split so that small-M layers (enc5-7, dec7, dec6) still fill 256 CUs.
+static void plan_splits(IGemmParams& p, size_t ws_floats_avail) {
+    const int bn = pick_bn(p.N);
+    const long tiles = (long)cdiv(p.M, 128) * cdiv(p.N, bn);
+    int splits = 1;
+    if (tiles < 384 && p.T >= 8) {
+        splits = (int)((768 + tiles - 1) / tiles);
+        if (splits > p.T / 4) splits = p.T / 4;
+        if (splits > 64) splits = 64;
+        if (splits < 1) splits = 1;
+    }
+    while (splits > 1 && (size_t)splits * p.M * p.N > ws_floats_avail) --splits;
+    p.steps_per_split = cdiv(p.T > 0 ? p.T : 1, splits);
+    p.splits = p.T > 0 ? cdiv(p.T, p.steps_per_split) : 1;
+}
+
+static int launch_igemm(IGemmParams& p, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0) return TG_OK;
+    const bool scalar = (p.C % 4) != 0;
+    p.Ktot = p.TH * p.TW * p.C;
+    p.nchunks = cdiv(p.C, 32);
+    p.T = scalar ? cdiv(p.Ktot, 32) : p.TH * p.TW * p.nchunks;
+    const int bn = pick_bn(p.N);
+    if (scalar) {
+        if (bn == 128) return launch_igemm_cfg<2, 2, 2, 2, true>(p, s);
+        if (bn == 64) return launch_igemm_cfg<2, 2, 2, 1, true>(p, s);
+        return launch_igemm_cfg<4, 1, 1, 1, true>(p, s);
+    }
+    if (bn == 128) return launch_igemm_cfg<2, 2, 2, 2, false>(p, s);
+    if (bn == 64) return launch_igemm_cfg<2, 2, 2, 1, false>(p, s);
+    return launch_igemm_cfg<4, 1, 1, 1, false>(p, s);
+}
+
+static int check_conv(const TgConv* g, const char* who) {
+    TG_REQUIRE(g != nullptr, "%s: null geometry", who);
+    TG_REQUIRE(g->B > 0 && g->H > 0 && g->W > 0 && g->Cin > 0 && g->Cout > 0, "%s: non-positive dims", who);
+    TG_REQUIRE(g->k > 0 && g->stride > 0 && g->pad >= 0, "%s: bad k/stride/pad", who);
+    TG_REQUIRE(g->Ho == (g->H + 2 * g->pad - g->k) / g->stride + 1 && g->Wo == (g->W + 2 * g->pad - g->k) / g->stride + 1,
+               "%s: Ho/Wo (%d,%d) inconsistent with H,W,k,s,p (%d,%d,%d,%d,%d)", who, g->Ho, g->Wo, g->H, g->W, g->k,
+               g->stride, g->pad);
+    TG_REQUIRE(g->Ho > 0 && g->Wo > 0, "%s: empty output", who);
+    TG_REQUIRE((int64_t)g->B * g->H * g->W * (int64_t)g->Cin < (1ll << 31) &&
+                   (int64_t)g->B * g->Ho * g->Wo * (int64_t)g->Cout < (1ll << 31),
+               "%s: tensor too large for 32-bit pixel indexing", who);
+    return TG_OK;
+}
+static bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
+
+// ---- forward ----------------------------------------------------------------------------------
+extern "C" size_t tg_conv_fwd_ws_bytes(const TgConv* g) {
+    if (!g) return 0;
+    // room for up to 8 slabs of the output (plan_splits shrinks to what fits)
+    size_t out = (size_t)g->B * g->Ho * g->Wo * g->Cout;
+    size_t cap = (size_t)64 << 20;  // floats
+    size_t want = out * 16;
+    return (want < cap ? want : cap) * sizeof(float);
+}
+
+extern "C" int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* bias,
+                           const float* ratio, int act, float slope, float* y, float* ws, size_t ws_bytes,
+                           tg_stream_t stream) {
+    int rc = check_conv(g, "tg_conv_fwd");
+    if (rc) return rc;
+    TG_REQUIRE(x && w && y, "tg_conv_fwd: null pointer");
+    TG_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), "tg_conv_fwd: pointers must be 16-byte aligned");
+    IGemmParams p = {};
+    p.src = x; p.amask = in_mask; p.wmat = w; p.bias = bias; p.rowscale = ratio; p.dst = y; p.ws = ws;
+    p.B = g->B; p.IH = g->H; p.IW = g->W; p.C = g->Cin;
+    p.OH = g->Ho; p.OW = g->Wo; p.N = g->Cout; p.M = g->B * g->Ho * g->Wo;
+    p.DH = g->Ho; p.DW = g->Wo; p.ds = 1; p.dy0 = 0; p.dx0 = 0;
+    p.TH = g->k; p.TW = g->k; p.ss = g->stride; p.tstep = 1; p.sy0 = -g->pad; p.sx0 = -g->pad;
+    p.KW = g->k; p.kstep = 1; p.ky0 = 0; p.kx0 = 0;
+    p.Kfull = g->k * g->k * g->Cin;
+    p.act = act; p.slope = slope; p.accumulate = 0;
+    p.Ktot = p.TH * p.TW * p.C; p.nchunks = cdiv(p.C, 32);
+    p.T = (p.C % 4) ? cdiv(p.Ktot, 32) : p.TH * p.TW * p.nchunks;
+    plan_splits(p, ws ? ws_bytes / sizeof(float) : 0);
+    return launch_igemm(p, (hipStream_t)stream);
+}
+
+// ---- dgrad ---------------------------------------------------------------------------------------
+// [Cout][T][Cin] -> [Cin][T][Cout]
+__global__ __launch_bounds__(256) void transpose_w_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                          int cout, int taps, int cin) {
+    const size_t total = (size_t)cout * taps * cin;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        int co = (int)(idx % cout);
+        size_t r = idx / cout;
+        int t = (int)(r % taps);
+        int ci = (int)(r / taps);
+        wt[idx] = w[((size_t)co * taps + t) * cin + ci];
+    }
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" size_t tg_conv_dgrad_ws_bytes(const TgConv* g) {
+    if (!g) return 0;
+    size_t wt = align_up((size_t)g->Cout * g->k * g->k * g->Cin, 64);
+    size_t out = (size_t)g->B * g->H * g->W * g->Cin;
+    size_t cap = (size_t)64 << 20;
+    size_t want = out * 16;
+    return (wt + (want < cap ? want : cap)) * sizeof(float);
+}
+
+extern "C" int tg_conv_dgrad(const TgConv* g, const float* dy, const float* w, const float* in_mask, float* dx,
+                             int accumulate, float* ws, size_t ws_bytes, tg_stream_t stream) {
+    int rc = check_conv(g, "tg_conv_dgrad");
+    if (rc) return rc;
+    TG_REQUIRE(dy && w && dx && ws, "tg_conv_dgrad: null pointer");
+    TG_REQUIRE(aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(ws), "tg_conv_dgrad: pointers must be 16-byte aligned");
+    const int taps = g->k * g->k;
+    const size_t wt_floats = align_up((size_t)g->Cout * taps * g->Cin, 64);
+    TG_REQUIRE(ws_bytes >= wt_floats * sizeof(float), "tg_conv_dgrad: workspace too small (%zu < %zu)", ws_bytes,
+               wt_floats * sizeof(float));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(transpose_w_kernel, dim3(ew_grid((int64_t)g->Cout * taps * g->Cin, 256)), dim3(256), 0, s, w, ws,
+                       g->Cout, taps, g->Cin);
+    TG_CHECK_LAUNCH("transpose_w_kernel");
+    float* ws2 = ws + wt_floats;
+    const size_t ws2_floats = ws_bytes / sizeof(float) - wt_floats;
+
+    const int st = g->stride;
+    for (int py = 0; py < st; ++py) {
+        for (int px = 0; px < st; ++px) {
+            IGemmParams p = {};
+            p.src = dy; p.amask = nullptr; p.wmat = ws; p.bias = nullptr; p.rowscale = in_mask; p.dst = dx; p.ws = ws2;
+            p.B = g->B; p.IH = g->Ho; p.IW = g->Wo; p.C = g->Cout;
+            p.OH = (g->H - py + st - 1) / st; p.OW = (g->W - px + st - 1) / st;
+            if (p.OH <= 0 || p.OW <= 0) continue;
+            p.N = g->Cin; p.M = g->B * p.OH * p.OW;
+            p.DH = g->H; p.DW = g->W; p.ds = st; p.dy0 = py; p.dx0 = px;
+            p.ky0 = (py + g->pad) % st; p.kx0 = (px + g->pad) % st;
+            p.TH = p.ky0 < g->k ? (g->k - p.ky0 + st - 1) / st : 0;
+            p.TW = p.kx0 < g->k ? (g->k - p.kx0 + st - 1) / st : 0;
+            p.ss = 1; p.tstep = -1;
+            p.sy0 = (py + g->pad - p.ky0) / st; p.sx0 = (px + g->pad - p.kx0) / st;
+            p.KW = g->k; p.kstep = st;
+            p.Kfull = taps * g->Cout;
+            p.act = TG_ACT_NONE; p.slope = 0.f; p.accumulate = accumulate;
+            p.Ktot = p.TH * p.TW * p.C; p.nchunks = cdiv(p.C, 32);
+            p.T = (p.C % 4) ? cdiv(p.Ktot, 32) : p.TH * p.TW * p.nchunks;
+            plan_splits(p, ws2_floats);
+            rc = launch_igemm(p, s);
+            if (rc) return rc;
+        }
+    }
+    return TG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: dW[cout][(tap,c)] = sum over pixels; both operands pixel-major ([k][m] LDS images, ds_read_b32)
+// ------------------------------------------------------------------------------------------------
+struct WgradParams {
+    const float* x;
+    const float* amask;
+    const float* dy;
+    float* out;  // [splits][Cout][Ktot]
+    int B, H, W, C, Ho, Wo, Cout, k, stride, pad;
+    int Mpix, Ktot, T, splits, steps_per_split;
+};
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR_A, bool SCALAR_B>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, BK = 32;
+    constexpr int A_V = BK * BM / 4 / 256;  // float4 loads per thread (vector path)
+    constexpr int B_V = BK * BN / 4 / 256;
+    constexpr int A_S = BK * BM / 256;      // scalar loads per thread
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(BN == 128, "column mapping assumes BN == 128");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                // [2][BK][BM]
+    float* Bs = smem + 2 * BK * BM;  // [2][BK][BN]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int n0 = blockIdx.x * BN, c0m = blockIdx.y * BM;
+    const int t_begin = blockIdx.z * p.steps_per_split;
+    const int t_end = min(p.T, t_begin + p.steps_per_split);
+
+    // B' columns owned by this thread: n = n0 + 4*(tid&31) + e  ->  (tap, c), fixed over the K loop
+    int bky[4], bkx[4], bc[4];
+    bool bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int n = n0 + 4 * (tid & 31) + e;
+        bv[e] = n < p.Ktot;
+        int nn = bv[e] ? n : 0;
+        int tap = nn / p.C;
+        bc[e] = nn - tap * p.C;
+        bky[e] = tap / p.k - p.pad;
+        bkx[e] = tap % p.k - p.pad;
+    }
+
+    f32x4 ra[SCALAR_A ? 1 : A_V];
+    float ras[SCALAR_A ? A_S : 1];
+    f32x4 rbv[B_V];
+
+    auto gload = [&](int t) {
+        const int mbase = t * BK;
+        // A' = dy rows
+        if constexpr (!SCALAR_A) {
+            constexpr int PER_ROW = BM / 4;
+#pragma unroll
+            for (int i = 0; i < A_V; ++i) {
+                int idx = tid + 256 * i;
+                int krow = idx / PER_ROW, c4 = idx % PER_ROW;
+                int m = mbase + krow, co = c0m + 4 * c4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m < p.Mpix && co < p.Cout) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + co);
+                ra[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_S; ++i) {
+                int idx = tid + 256 * i;
+                int krow = idx / BM, col = idx % BM;
+                int m = mbase + krow, co = c0m + col;
+                ras[i] = (m < p.Mpix && co < p.Cout) ? p.dy[(size_t)m * p.Cout + co] : 0.f;
+            }
+        }
+        // B' = tap-shifted, masked input rows
+#pragma unroll
+        for (int i = 0; i < B_V; ++i) {
+            int krow = (tid >> 5) + 8 * i;
+            int m = mbase + krow;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < p.Mpix) {
+                int ox = m % p.Wo;
+                int tt = m / p.Wo;
+                int oy = tt % p.Ho;
+                int b = tt / p.Ho;
+                if constexpr (!SCALAR_B) {
+                    int iy = oy * p.stride + bky[0], ix = ox * p.stride + bkx[0];
+                    if (bv[0] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                        size_t pix = ((size_t)b * p.H + iy) * p.W + ix;
+                        v = *reinterpret_cast<const f32x4*>(p.x + pix * p.C + bc[0]);
+                        if (p.amask) v *= p.amask[pix];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int iy = oy * p.stride + bky[e], ix = ox * p.stride + bkx[e];
+                        if (bv[e] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                            size_t pix = ((size_t)b * p.H + iy) * p.W + ix;
+                            float sv = p.x[pix * p.C + bc[e]];
+                            if (p.amask) sv *= p.amask[pix];
+                            v[e] = sv;
+                        }
+                    }
+                }
+            }
+            rbv[i] = v;
+        }
+    };
+    auto sstore = [&](int buf) {
+        float* Ab = As + buf * BK * BM;
+        float* Bb = Bs + buf * BK * BN;
+        if constexpr (!SCALAR_A) {
+            constexpr int PER_ROW = BM / 4;
+#pragma unroll
+            for (int i = 0; i < A_V; ++i) {
+                int idx = tid + 256 * i;
+                int krow = idx / PER_ROW, c4 = idx % PER_ROW;
+                *reinterpret_cast<f32x4*>(Ab + krow * BM + 4 * c4) = ra[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_S; ++i) {
+                int idx = tid + 256 * i;
+                Ab[idx] = ras[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_V; ++i) {
+            int krow = (tid >> 5) + 8 * i;
+            *reinterpret_cast<f32x4*>(Bb + krow * BN + 4 * (tid & 31)) = rbv[i];
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int acol = wm * WM * 32 + (lane & 31);
+    const int bcol = wn * WN * 32 + (lane & 31);
+    const int kh = lane >> 5;
+
+    if (t_begin < t_end) {
+        gload(t_begin);
+        sstore(0);
+        __syncthreads();
+        for (int t = t_begin; t < t_end; ++t) {
+            const int cur = (t - t_begin) & 1;
+            const bool more = (t + 1) < t_end;
+            if (more) gload(t + 1);
+            const float* Ab = As + cur * BK * BM;
+            const float* Bb = Bs + cur * BK * BN;
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                float a[WM], b[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a[i] = Ab[(2 * kk + kh) * BM + acol + 32 * i];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) b[j] = Bb[(2 * kk + kh) * BN + bcol + 32 * j];
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) sstore(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    float* out = p.out + (size_t)blockIdx.z * p.Cout * p.Ktot;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int co = c0m + (wm * WM + i) * 32 + row;
+            if (co >= p.Cout) continue;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
+                if (n < p.Ktot) out[(size_t)co * p.Ktot + n] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                          size_t n, int splits) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += ws[(size_t)z * n + idx];
+        out[idx] = v;
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool SA, bool SB>
+static int launch_wgrad_cfg(const WgradParams& p, hipStream_t s) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    constexpr size_t lds = (size_t)2 * 32 * (BM + BN) * sizeof(float);
+    static bool attr_done = false;
+    auto kern = wgrad_kernel<WAVES_M, WAVES_N, WM, WN, SA, SB>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            tg_set_error("wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return TG_ERR_LAUNCH;
+        }
+        attr_done = true;
+    }
+    dim3 grid(cdiv(p.Ktot, BN), cdiv(p.Cout, BM), p.splits);
+    {
+        const double by = 4.0 * ((double)p.B * p.H * p.W * p.C + (double)p.Mpix * p.Cout + (double)p.Cout * p.Ktot +
+                                 (double)p.Mpix + (p.amask ? (double)p.B * p.H * p.W : 0.0));
+        ProfScope ps(s, 1, 2.0 * p.Mpix * (double)p.Cout * p.Ktot, by);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    }
+    TG_CHECK_LAUNCH("wgrad_kernel");
+    return TG_OK;
+}
+
+static int wgrad_bm(const TgConv* g) {
+    if (g->Cout % 4 != 0 || g->Cout < 32) return 32;
+    if (g->Cout >= 128 && g->Cin % 4 == 0) return 128;
+    return 64;
+}
+static void wgrad_plan(const TgConv* g, int* splits, int* steps_per_split, int* T) {
+    const int Mpix = g->B * g->Ho * g->Wo;
+    const int Ktot = g->k * g->k * g->Cin;
+    const int bm = wgrad_bm(g);
+    const long tiles = (long)cdiv(g->Cout, bm) * cdiv(Ktot, 128);
+    *T = cdiv(Mpix, 32);
+    int sp = (int)((1024 + tiles - 1) / tiles);
+    if (sp > cdiv(*T, 4)) sp = cdiv(*T, 4);
+    if (sp > 512) sp = 512;
+    if (sp < 1) sp = 1;
+    *steps_per_split = cdiv(*T, sp);
+    *splits = cdiv(*T, *steps_per_split);
+}
+
+int tg_colsum_launch(const float* x, int64_t rows, int C, float* out, float* ws, hipStream_t s);  // pointwise.hip
+size_t tg_colsum_ws_floats(int64_t rows, int C);
+
+extern "C" size_t tg_conv_wgrad_ws_bytes(const TgConv* g) {
+    if (!g) return 0;
+    int splits, sps, T;
+    wgrad_plan(g, &splits, &sps, &T);
+    size_t slabs = align_up((size_t)splits * g->Cout * g->k * g->k * g->Cin, 64);
+    return (slabs + tg_colsum_ws_floats((int64_t)g->B * g->Ho * g->Wo, g->Cout)) * sizeof(float);
+}
+
+extern "C" int tg_conv_wgrad(const TgConv* g, const float* x, const float* in_mask, const float* dy, float* dw,
+                             float* db, float* ws, size_t ws_bytes, tg_stream_t stream) {
+    int rc = check_conv(g, "tg_conv_wgrad");
+    if (rc) return rc;
+    TG_REQUIRE(x && dy && dw && ws, "tg_conv_wgrad: null pointer");
+    TG_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(ws), "tg_conv_wgrad: pointers must be 16-byte aligned");
+    TG_REQUIRE(ws_bytes >= tg_conv_wgrad_ws_bytes(g), "tg_conv_wgrad: workspace too small (%zu < %zu)", ws_bytes,
+               tg_conv_wgrad_ws_bytes(g));
+    hipStream_t s = (hipStream_t)stream;
+    WgradParams p = {};
+    p.x = x; p.amask = in_mask; p.dy = dy;
+    p.B = g->B; p.H = g->H; p.W = g->W; p.C = g->Cin; p.Ho = g->Ho; p.Wo = g->Wo; p.Cout = g->Cout;
+    p.k = g->k; p.stride = g->stride; p.pad = g->pad;
+    p.Mpix = g->B * g->Ho * g->Wo; p.Ktot = g->k * g->k * g->Cin;
+    wgrad_plan(g, &p.splits, &p.steps_per_split, &p.T);
+    p.out = p.splits > 1 ? ws : dw;
+    const int bm = wgrad_bm(g);
+    const bool sb = (g->Cin % 4) != 0;
+    if (bm == 128) rc = launch_wgrad_cfg<2, 2, 2, 2, false, false>(p, s);
+    else if (bm == 64) rc = sb ? launch_wgrad_cfg<1, 4, 2, 1, false, true>(p, s) : launch_wgrad_cfg<1, 4, 2, 1, false, false>(p, s);
+    else rc = sb ? launch_wgrad_cfg<1, 4, 1, 1, true, true>(p, s) : launch_wgrad_cfg<1, 4, 1, 1, true, false>(p, s);
+    if (rc) return rc;
+    const size_t n = (size_t)g->Cout * p.Ktot;
+    if (p.splits > 1) {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid((int64_t)n, 256)), dim3(256), 0, s, ws, dw, n, p.splits);
+        TG_CHECK_LAUNCH("slab_reduce_kernel");
+    }
+    if (db) {
+        float* ws2 = ws + align_up((size_t)p.splits * n, 64);
+        rc = tg_colsum_launch(dy, (int64_t)p.Mpix, g->Cout, db, ws2, s);
+        if (rc) return rc;
+    }
+    return TG_OK;
+}
+
+__global__ __launch_bounds__(256) void fold_cin_kernel(const float* __restrict__ w3, float* __restrict__ w1, int n, int cin) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+        float v = 0.f;
+        for (int c = 0; c < cin; ++c) v += w3[(size_t)idx * cin + c];
+        w1[idx] = v;
+    }
+}
+extern "C" int tg_fold_cin(const float* w3, int cout, int taps, int cin, float* w1, tg_stream_t stream) {
+    TG_REQUIRE(w3 && w1 && cout > 0 && taps > 0 && cin > 0, "tg_fold_cin: bad arguments");
+    int n = cout * taps;
+    hipLaunchKernelGGL(fold_cin_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, w3, w1, n, cin);
+    TG_CHECK_LAUNCH("fold_cin_kernel");
+    return TG_OK;
+}

@@ -1,0 +1,964 @@
+// Bandwidth-bound kernels of the train step: mask path, BatchNorm(+act) fwd/bwd, bilinear-up (+) concat,
+// generator head, max-pool, loss reductions with their gradients, Adam.  All NHWC, fp32, coalesced along
+// the channel (or pixel, for 1-channel images) axis; reductions are two-stage (per-block partials in a
+// caller workspace, fixed-order final sum in fp64) so results are bitwise reproducible run to run.
+#include <math.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+void tg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* tg_last_error(void) { return g_err; }
+extern "C" int tg_version(void) { return 100; }
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline hipStream_t S(tg_stream_t s) { return (hipStream_t)s; }
+
+// =================================================================================================
+// column reductions over a [rows][C] matrix (C <= 1024): thread = (row lane, column), partial[block][q][c]
+// =================================================================================================
+constexpr int CR_MAXPASS = 4;
+
+struct ColGeom {
+    int cpp;        // columns per pass = min(C, 256)
+    int rlanes;     // row lanes = 256 / cpp
+    int npass;      // ceil(C / cpp)
+    int grid;       // blocks
+    int64_t rows_per_block;
+};
+static ColGeom col_geom(int64_t rows, int C) {
+    ColGeom g;
+    g.cpp = C < 256 ? C : 256;
+    g.rlanes = 256 / g.cpp;
+    g.npass = cdiv(C, g.cpp);
+    int64_t want = cdiv64(rows, (int64_t)g.rlanes * 16);
+    if (want > 1024) want = 1024;
+    if (want < 1) want = 1;
+    g.rows_per_block = cdiv64(rows, want);
+    g.grid = (int)cdiv64(rows, g.rows_per_block);
+    return g;
+}
+
+template <int NQ, class F>
+__global__ __launch_bounds__(256) void colreduce_kernel(F f, int64_t rows, int C, int cpp, int rlanes,
+                                                        int64_t rows_per_block, float* __restrict__ partial) {
+    __shared__ float red[NQ][256];
+    const int tid = threadIdx.x;
+    const int col = tid % cpp, rl = tid / cpp;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    float q[CR_MAXPASS][NQ];
+#pragma unroll
+    for (int ps = 0; ps < CR_MAXPASS; ++ps)
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) q[ps][i] = 0.f;
+    if (rl < rlanes) {
+        for (int64_t r = r0 + rl; r < r1; r += rlanes) {
+#pragma unroll
+            for (int ps = 0; ps < CR_MAXPASS; ++ps) {
+                int c = col + ps * cpp;
+                if (c < C) f(r, c, q[ps]);
+            }
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < CR_MAXPASS; ++ps) {
+        const int c = col + ps * cpp;
+        if (ps * cpp >= C) break;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) red[i][tid] = (rl < rlanes) ? q[ps][i] : 0.f;
+        __syncthreads();
+        if (rl == 0 && c < C) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                float s = 0.f;
+                for (int l = 0; l < rlanes; ++l) s += red[i][l * cpp + col];
+                partial[((size_t)blockIdx.x * NQ + i) * C + c] = s;
+            }
+        }
+    }
+}
+
+// ---- plain column sum (conv bias gradient) --------------------------------------------------------
+struct ColSumF {
+    const float* x;
+    int C;
+    __device__ void operator()(int64_t r, int c, float (&q)[1]) const { q[0] += x[r * C + c]; }
+};
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                           float* __restrict__ out) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * C + c];
+    out[c] = (float)s;
+}
+size_t tg_colsum_ws_floats(int64_t rows, int C) {
+    ColGeom g = col_geom(rows, C);
+    return align_up((size_t)g.grid * C, 64);
+}
+int tg_colsum_launch(const float* x, int64_t rows, int C, float* out, float* ws, hipStream_t s) {
+    TG_REQUIRE(C >= 1 && C <= 1024, "colsum: C=%d out of range [1,1024]", C);
+    ColGeom g = col_geom(rows, C);
+    ColSumF f{x, C};
+    hipLaunchKernelGGL((colreduce_kernel<1, ColSumF>), dim3(g.grid), dim3(256), 0, s, f, rows, C, g.cpp, g.rlanes,
+                       g.rows_per_block, ws);
+    TG_CHECK_LAUNCH("colsum");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, g.grid, C, out);
+    TG_CHECK_LAUNCH("colsum_final");
+    return TG_OK;
+}
+
+// =================================================================================================
+// mask path
+// =================================================================================================
+__global__ __launch_bounds__(256) void mask_update_kernel(const float* __restrict__ mask, int B, int H, int W, int k,
+                                                          int stride, int pad, int Ho, int Wo,
+                                                          float* __restrict__ mask_out, float* __restrict__ ratio) {
+    const int64_t total = (int64_t)B * Ho * Wo;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int ox = (int)(idx % Wo);
+        int64_t t = idx / Wo;
+        int oy = (int)(t % Ho);
+        int b = (int)(t / Ho);
+        float s = 0.f;
+        for (int ky = 0; ky < k; ++ky) {
+            int iy = oy * stride - pad + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                int ix = ox * stride - pad + kx;
+                if (ix < 0 || ix >= W) continue;
+                s += mask[((int64_t)b * H + iy) * W + ix];
+            }
+        }
+        const float on = s > 0.f ? 1.f : 0.f;
+        mask_out[idx] = on;
+        ratio[idx] = (float)(k * k) / (s + 1e-8f) * on;
+    }
+}
+extern "C" int tg_mask_update(const float* mask, int B, int H, int W, int k, int stride, int pad, int Ho, int Wo,
+                              float* mask_out, float* ratio, tg_stream_t stream) {
+    TG_REQUIRE(mask && mask_out && ratio, "tg_mask_update: null pointer");
+    TG_REQUIRE(B > 0 && H > 0 && W > 0 && k > 0 && stride > 0 && pad >= 0, "tg_mask_update: bad dims");
+    TG_REQUIRE(Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1 && Ho > 0 && Wo > 0,
+               "tg_mask_update: Ho/Wo inconsistent");
+    hipLaunchKernelGGL(mask_update_kernel, dim3(ew_grid((int64_t)B * Ho * Wo, 256)), dim3(256), 0, S(stream), mask, B, H, W,
+                       k, stride, pad, Ho, Wo, mask_out, ratio);
+    TG_CHECK_LAUNCH("mask_update_kernel");
+    return TG_OK;
+}
+
+__host__ __device__ inline int floordiv2(int a) { return a >= 0 ? a / 2 : -((-a + 1) / 2); }
+
+__global__ __launch_bounds__(256) void mask_up_merge_kernel(const float* __restrict__ up, const float* __restrict__ skip,
+                                                            int B, int h, int w, int H, int W, int offy, int offx,
+                                                            float* __restrict__ out) {
+    const int64_t total = (int64_t)B * H * W;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int X = (int)(idx % W);
+        int64_t t = idx / W;
+        int Y = (int)(t % H);
+        int b = (int)(t / H);
+        int yu = Y - offy, xu = X - offx;
+        float v = 0.f;
+        if (yu >= 0 && yu < 2 * h && xu >= 0 && xu < 2 * w) v = up[((int64_t)b * h + (yu >> 1)) * w + (xu >> 1)];
+        out[idx] = fmaxf(v, skip[idx]);
+    }
+}
+extern "C" int tg_mask_up_merge(const float* up_mask, const float* skip_mask, int B, int h, int w, int H, int W,
+                                float* out, tg_stream_t stream) {
+    TG_REQUIRE(up_mask && skip_mask && out && B > 0 && h > 0 && w > 0 && H > 0 && W > 0, "tg_mask_up_merge: bad arguments");
+    hipLaunchKernelGGL(mask_up_merge_kernel, dim3(ew_grid((int64_t)B * H * W, 256)), dim3(256), 0, S(stream), up_mask,
+                       skip_mask, B, h, w, H, W, floordiv2(H - 2 * h), floordiv2(W - 2 * w), out);
+    TG_CHECK_LAUNCH("mask_up_merge_kernel");
+    return TG_OK;
+}
+
+// =================================================================================================
+// BatchNorm
+// =================================================================================================
+// shifted sums: d = y - y[0][c]  ->  sum d, sum d^2 (no catastrophic cancellation when |mean| >> std)
+struct BnStatF {
+    const float* y;
+    int C;
+    __device__ void operator()(int64_t r, int c, float (&q)[2]) const {
+        float d = y[r * C + c] - y[c];
+        q[0] += d;
+        q[1] += d * d;
+    }
+};
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                          const float* __restrict__ y, int64_t rows, float eps,
+                                                          float momentum, float* __restrict__ mean_out,
+                                                          float* __restrict__ rstd_out, float* __restrict__ rm,
+                                                          float* __restrict__ rv, int64_t* __restrict__ nbt) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    double s = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        s += (double)partial[((size_t)b * 2 + 0) * C + c];
+        s2 += (double)partial[((size_t)b * 2 + 1) * C + c];
+    }
+    const double n = (double)rows;
+    const double md = s / n;
+    double var = s2 / n - md * md;
+    if (var < 0.0) var = 0.0;
+    const double mean = (double)y[c] + md;
+    mean_out[c] = (float)mean;
+    rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rm) rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * mean);
+    if (rv) rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * var * (n / (n - 1.0)));
+}
+extern "C" size_t tg_bn_ws_bytes(int64_t rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    ColGeom g = col_geom(rows, C);
+    return align_up((size_t)g.grid * 2 * C, 64) * sizeof(float);
+}
+extern "C" int tg_bn_stats(const float* y, int64_t rows, int C, float eps, float momentum, float* save_mean,
+                           float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           float* ws, size_t ws_bytes, tg_stream_t stream) {
+    TG_REQUIRE(y && save_mean && save_rstd && ws, "tg_bn_stats: null pointer");
+    TG_REQUIRE(C >= 1 && C <= 1024, "tg_bn_stats: C=%d out of range [1,1024]", C);
+    TG_REQUIRE(rows > 1, "tg_bn_stats: Expected more than 1 value per channel when training (rows=%lld)", (long long)rows);
+    TG_REQUIRE(ws_bytes >= tg_bn_ws_bytes(rows, C), "tg_bn_stats: workspace too small");
+    ColGeom g = col_geom(rows, C);
+    BnStatF f{y, C};
+    hipLaunchKernelGGL((colreduce_kernel<2, BnStatF>), dim3(g.grid), dim3(256), 0, S(stream), f, rows, C, g.cpp, g.rlanes,
+                       g.rows_per_block, ws);
+    TG_CHECK_LAUNCH("bn_stats");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), ws, g.grid, C, y, rows, eps,
+                       momentum, save_mean, save_rstd, running_mean, running_var, num_batches_tracked);
+    TG_CHECK_LAUNCH("bn_finalize");
+    return TG_OK;
+}
+
+__global__ __launch_bounds__(256) void bn_eval_stats_kernel(const float* rm, const float* rv, int C, float eps, float* mean,
+                                                            float* rstd) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = rm[c];
+    rstd[c] = 1.0f / sqrtf(rv[c] + eps);
+}
+extern "C" int tg_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* mean,
+                                float* rstd, tg_stream_t stream) {
+    TG_REQUIRE(running_mean && running_var && mean && rstd && C > 0, "tg_bn_eval_stats: bad arguments");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), running_mean, running_var, C, eps,
+                       mean, rstd);
+    TG_CHECK_LAUNCH("bn_eval_stats_kernel");
+    return TG_OK;
+}
+
+// vectorised along channels when C % 4 == 0
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, int64_t total, int C,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int act, float slope, float* __restrict__ out) {
+    if constexpr (VEC) {
+        const int64_t n4 = total / 4;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            const int c = (int)((i * 4) % C);
+            f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float xh = (v[e] - mean[c + e]) * rstd[c + e];
+                o[e] = apply_act(xh * gamma[c + e] + beta[c + e], act, slope);
+            }
+            reinterpret_cast<f32x4*>(out)[i] = o;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            const int c = (int)(i % C);
+            float xh = (y[i] - mean[c]) * rstd[c];
+            out[i] = apply_act(xh * gamma[c] + beta[c], act, slope);
+        }
+    }
+}
+extern "C" int tg_bn_act_fwd(const float* y, int64_t rows, int C, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, int act, float slope, float* out, tg_stream_t stream) {
+    TG_REQUIRE(y && mean && rstd && gamma && beta && out && rows > 0 && C > 0, "tg_bn_act_fwd: bad arguments");
+    const int64_t total = rows * C;
+    if (C % 4 == 0) {
+        hipLaunchKernelGGL((bn_act_fwd_kernel<true>), dim3(ew_grid(total / 4, 256)), dim3(256), 0, S(stream), y, total, C, mean,
+                           rstd, gamma, beta, act, slope, out);
+    } else {
+        hipLaunchKernelGGL((bn_act_fwd_kernel<false>), dim3(ew_grid(total, 256)), dim3(256), 0, S(stream), y, total, C, mean,
+                           rstd, gamma, beta, act, slope, out);
+    }
+    TG_CHECK_LAUNCH("bn_act_fwd_kernel");
+    return TG_OK;
+}
+
+__device__ __forceinline__ float act_grad(float z, int act, float slope) {
+    if (act == TG_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == TG_ACT_LEAKY) return z > 0.f ? 1.f : slope;
+    return 1.f;
+}
+struct BnBwdF {
+    const float* dout;
+    const float* y;
+    const float* mean;
+    const float* rstd;
+    const float* gamma;
+    const float* beta;
+    int C, act;
+    float slope;
+    __device__ void operator()(int64_t r, int c, float (&q)[2]) const {
+        float xh = (y[r * C + c] - mean[c]) * rstd[c];
+        float g = dout[r * C + c] * act_grad(xh * gamma[c] + beta[c], act, slope);
+        q[0] += g;
+        q[1] += g * xh;
+    }
+};
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        s += (double)partial[((size_t)b * 2 + 0) * C + c];
+        s2 += (double)partial[((size_t)b * 2 + 1) * C + c];
+    }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)s2;
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                           int64_t rows, int C, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int act, float slope,
+                                                           const float* __restrict__ ratio, const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, float* __restrict__ dy) {
+    const int64_t total = rows * C;
+    const float inv_n = 1.0f / (float)rows;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t r = i / C;
+        float xh = (y[i] - mean[c]) * rstd[c];
+        float g = dout[i] * act_grad(xh * gamma[c] + beta[c], act, slope);
+        float v = gamma[c] * rstd[c] * (g - dbeta[c] * inv_n - xh * dgamma[c] * inv_n);
+        if (ratio) v *= ratio[r];
+        dy[i] = v;
+    }
+}
+extern "C" int tg_bn_act_bwd(const float* dout, const float* y, int64_t rows, int C, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, int act, float slope, const float* ratio, float* dy,
+                             float* dgamma, float* dbeta, float* ws, size_t ws_bytes, tg_stream_t stream) {
+    TG_REQUIRE(dout && y && mean && rstd && gamma && beta && dy && dgamma && dbeta && ws, "tg_bn_act_bwd: null pointer");
+    TG_REQUIRE(C >= 1 && C <= 1024 && rows > 0, "tg_bn_act_bwd: bad dims");
+    TG_REQUIRE(ws_bytes >= tg_bn_ws_bytes(rows, C), "tg_bn_act_bwd: workspace too small");
+    ColGeom g = col_geom(rows, C);
+    BnBwdF f{dout, y, mean, rstd, gamma, beta, C, act, slope};
+    hipLaunchKernelGGL((colreduce_kernel<2, BnBwdF>), dim3(g.grid), dim3(256), 0, S(stream), f, rows, C, g.cpp, g.rlanes,
+                       g.rows_per_block, ws);
+    TG_CHECK_LAUNCH("bn_bwd_reduce");
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), ws, g.grid, C, dgamma, dbeta);
+    TG_CHECK_LAUNCH("bn_bwd_final");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * C, 256)), dim3(256), 0, S(stream), dout, y, rows, C, mean,
+                       rstd, gamma, beta, act, slope, ratio, dgamma, dbeta, dy);
+    TG_CHECK_LAUNCH("bn_bwd_apply");
+    return TG_OK;
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                      int64_t rows, int C, int act, float slope,
+                                                      const float* __restrict__ ratio, float* __restrict__ din) {
+    const int64_t total = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float v = dout[i] * act_grad(out[i], act, slope);
+        if (ratio) v *= ratio[i / C];
+        din[i] = v;
+    }
+}
+extern "C" int tg_act_bwd(const float* dout, const float* out, int64_t rows, int C, int act, float slope, const float* ratio,
+                          float* din, tg_stream_t stream) {
+    TG_REQUIRE(dout && din && rows > 0 && C > 0, "tg_act_bwd: bad arguments");
+    TG_REQUIRE(out || act == TG_ACT_NONE, "tg_act_bwd: activation needs the forward output");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(rows * C, 256)), dim3(256), 0, S(stream), dout, out ? out : dout, rows, C,
+                       act, slope, ratio, din);
+    TG_CHECK_LAUNCH("act_bwd_kernel");
+    return TG_OK;
+}
+
+// =================================================================================================
+// bilinear x2 (align_corners=False) (+) concat, and its adjoint
+// =================================================================================================
+struct Lerp {
+    int i0, i1;
+    float l0, l1;
+};
+// PyTorch area_pixel_compute_source_index for scale 0.5, align_corners=False
+__device__ __forceinline__ Lerp lerp_src(int dst, int n) {
+    float src = 0.5f * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    Lerp L;
+    L.i0 = (int)src;
+    L.i1 = L.i0 + (L.i0 < n - 1 ? 1 : 0);
+    L.l1 = src - (float)L.i0;
+    L.l0 = 1.f - L.l1;
+    return L;
+}
+
+template <int V>  // V = 4 (float4 over channels) or 1
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict__ up, const float* __restrict__ skip, int B,
+                                                        int h, int w, int Cu, int H, int W, int Cs, int offy, int offx,
+                                                        float* __restrict__ out) {
+    const int Ct = Cu + Cs;
+    const int cv = Ct / V;
+    const int64_t total = (int64_t)B * H * W * cv;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % cv) * V;
+        const int64_t pix = idx / cv;
+        const int X = (int)(pix % W);
+        const int64_t t = pix / W;
+        const int Y = (int)(t % H);
+        const int b = (int)(t / H);
+        float o[V];
+        if (c >= Cu) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = skip[pix * Cs + (c - Cu) + e];
+        } else {
+            const int yu = Y - offy, xu = X - offx;
+            if (yu < 0 || yu >= 2 * h || xu < 0 || xu >= 2 * w) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] = 0.f;
+            } else {
+                const Lerp ly = lerp_src(yu, h), lx = lerp_src(xu, w);
+                const float* r0 = up + (((int64_t)b * h + ly.i0) * w) * Cu + c;
+                const float* r1 = up + (((int64_t)b * h + ly.i1) * w) * Cu + c;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    float a = r0[(int64_t)lx.i0 * Cu + e], bb = r0[(int64_t)lx.i1 * Cu + e];
+                    float cc = r1[(int64_t)lx.i0 * Cu + e], d = r1[(int64_t)lx.i1 * Cu + e];
+                    o[e] = ly.l0 * (lx.l0 * a + lx.l1 * bb) + ly.l1 * (lx.l0 * cc + lx.l1 * d);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) out[pix * Ct + c + e] = o[e];
+    }
+}
+extern "C" int tg_upcat_fwd(const float* up, const float* skip, int B, int h, int w, int Cu, int H, int W, int Cs, float* out,
+                            tg_stream_t stream) {
+    TG_REQUIRE(up && out && B > 0 && h > 0 && w > 0 && Cu > 0 && H > 0 && W > 0 && Cs >= 0, "tg_upcat_fwd: bad arguments");
+    TG_REQUIRE(Cs == 0 || skip, "tg_upcat_fwd: skip is NULL but Cs > 0");
+    const int offy = floordiv2(H - 2 * h), offx = floordiv2(W - 2 * w);
+    const int Ct = Cu + Cs;
+    if (Cu % 4 == 0 && Cs % 4 == 0) {
+        hipLaunchKernelGGL((upcat_fwd_kernel<4>), dim3(ew_grid((int64_t)B * H * W * (Ct / 4), 256)), dim3(256), 0, S(stream), up,
+                           skip, B, h, w, Cu, H, W, Cs, offy, offx, out);
+    } else {
+        hipLaunchKernelGGL((upcat_fwd_kernel<1>), dim3(ew_grid((int64_t)B * H * W * Ct, 256)), dim3(256), 0, S(stream), up, skip,
+                           B, h, w, Cu, H, W, Cs, offy, offx, out);
+    }
+    TG_CHECK_LAUNCH("upcat_fwd_kernel");
+    return TG_OK;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void upcat_bwd_up_kernel(const float* __restrict__ dout, int B, int h, int w, int Cu, int H,
+                                                           int W, int Ct, int offy, int offx, float* __restrict__ dup) {
+    const int cv = Cu / V;
+    const int64_t total = (int64_t)B * h * w * cv;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % cv) * V;
+        const int64_t pix = idx / cv;
+        const int x = (int)(pix % w);
+        const int64_t t = pix / w;
+        const int y = (int)(t % h);
+        const int b = (int)(t / h);
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int yu = 2 * y - 1; yu <= 2 * y + 2; ++yu) {
+            const int Y = yu + offy;
+            if (yu < 0 || yu >= 2 * h || Y < 0 || Y >= H) continue;
+            const Lerp ly = lerp_src(yu, h);
+            const float wy = (ly.i0 == y ? ly.l0 : 0.f) + (ly.i1 == y ? ly.l1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int xu = 2 * x - 1; xu <= 2 * x + 2; ++xu) {
+                const int X = xu + offx;
+                if (xu < 0 || xu >= 2 * w || X < 0 || X >= W) continue;
+                const Lerp lx = lerp_src(xu, w);
+                const float wx = (lx.i0 == x ? lx.l0 : 0.f) + (lx.i1 == x ? lx.l1 : 0.f);
+                if (wx == 0.f) continue;
+                const float* src = dout + (((int64_t)b * H + Y) * W + X) * Ct + c;
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += wy * wx * src[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) dup[pix * Cu + c + e] = acc[e];
+    }
+}
+__global__ __launch_bounds__(256) void slice_channels_kernel(const float* __restrict__ src, int64_t rows, int Ct, int c0,
+                                                             int Cs, float* __restrict__ dst) {
+    const int64_t total = rows * Cs;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cs);
+        const int64_t r = i / Cs;
+        dst[i] = src[r * Ct + c0 + c];
+    }
+}
+extern "C" int tg_upcat_bwd(const float* dout, int B, int h, int w, int Cu, int H, int W, int Cs, float* dup, float* dskip,
+                            tg_stream_t stream) {
+    TG_REQUIRE(dout && dup && B > 0 && h > 0 && w > 0 && Cu > 0 && H > 0 && W > 0 && Cs >= 0, "tg_upcat_bwd: bad arguments");
+    const int offy = floordiv2(H - 2 * h), offx = floordiv2(W - 2 * w);
+    const int Ct = Cu + Cs;
+    if (Cu % 4 == 0 && Ct % 4 == 0) {
+        hipLaunchKernelGGL((upcat_bwd_up_kernel<4>), dim3(ew_grid((int64_t)B * h * w * (Cu / 4), 256)), dim3(256), 0, S(stream),
+                           dout, B, h, w, Cu, H, W, Ct, offy, offx, dup);
+    } else {
+        hipLaunchKernelGGL((upcat_bwd_up_kernel<1>), dim3(ew_grid((int64_t)B * h * w * Cu, 256)), dim3(256), 0, S(stream), dout,
+                           B, h, w, Cu, H, W, Ct, offy, offx, dup);
+    }
+    TG_CHECK_LAUNCH("upcat_bwd_up_kernel");
+    if (Cs > 0 && dskip) {
+        hipLaunchKernelGGL(slice_channels_kernel, dim3(ew_grid((int64_t)B * H * W * Cs, 256)), dim3(256), 0, S(stream), dout,
+                           (int64_t)B * H * W, Ct, Cu, Cs, dskip);
+        TG_CHECK_LAUNCH("slice_channels_kernel");
+    }
+    return TG_OK;
+}
+
+// =================================================================================================
+// generator head
+// =================================================================================================
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void sigcomp_fwd_kernel(const float* __restrict__ z, const float* __restrict__ x,
+                                                          const float* __restrict__ m, int64_t n, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float s = sigmoidf_(z[i]);
+        out[i] = s * (1.f - m[i]) + x[i] * m[i];
+    }
+}
+extern "C" int tg_sigmoid_composite_fwd(const float* logits, const float* x, const float* mask, int64_t n, float* out,
+                                        tg_stream_t stream) {
+    TG_REQUIRE(logits && x && mask && out && n > 0, "tg_sigmoid_composite_fwd: bad arguments");
+    hipLaunchKernelGGL(sigcomp_fwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), logits, x, mask, n, out);
+    TG_CHECK_LAUNCH("sigcomp_fwd_kernel");
+    return TG_OK;
+}
+__global__ __launch_bounds__(256) void sigcomp_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                          const float* __restrict__ m, int64_t n, float* __restrict__ dz,
+                                                          float* __restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float s = sigmoidf_(z[i]);
+        float g = dout[i];
+        dz[i] = g * (1.f - m[i]) * (1.f - s) * s;
+        if (dx) dx[i] = g * m[i];
+    }
+}
+extern "C" int tg_sigmoid_composite_bwd(const float* dout, const float* logits, const float* mask, int64_t n, float* dlogits,
+                                        float* dx, tg_stream_t stream) {
+    TG_REQUIRE(dout && logits && mask && dlogits && n > 0, "tg_sigmoid_composite_bwd: bad arguments");
+    hipLaunchKernelGGL(sigcomp_bwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), dout, logits, mask, n, dlogits, dx);
+    TG_CHECK_LAUNCH("sigcomp_bwd_kernel");
+    return TG_OK;
+}
+
+// =================================================================================================
+// 2x2 max-pool (VGG trunk)
+// =================================================================================================
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C,
+                                                           float* __restrict__ out) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)B * Ho * Wo * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        int64_t t = idx / C;
+        const int ox = (int)(t % Wo);
+        t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const float* p0 = x + (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+        float v = p0[0];
+        v = fmaxf(v, p0[C]);
+        v = fmaxf(v, p0[(int64_t)W * C]);
+        v = fmaxf(v, p0[(int64_t)W * C + C]);
+        out[idx] = v;
+    }
+}
+extern "C" int tg_maxpool2_fwd(const float* x, int B, int H, int W, int C, float* out, tg_stream_t stream) {
+    TG_REQUIRE(x && out && B > 0 && H > 1 && W > 1 && C > 0, "tg_maxpool2_fwd: bad arguments");
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_grid((int64_t)B * (H / 2) * (W / 2) * C, 256)), dim3(256), 0, S(stream), x,
+                       B, H, W, C, out);
+    TG_CHECK_LAUNCH("maxpool2_fwd_kernel");
+    return TG_OK;
+}
+// gradient goes to the first maximum in window scan order (ATen CPU max_pool2d)
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x, int B,
+                                                           int H, int W, int C, float* __restrict__ dx) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        int64_t t = idx / C;
+        const int ix = (int)(t % W);
+        t /= W;
+        const int iy = (int)(t % H);
+        const int b = (int)(t / H);
+        const int oy = iy >> 1, ox = ix >> 1;
+        float g = 0.f;
+        if (oy < Ho && ox < Wo) {
+            const float* p0 = x + (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+            const float v[4] = {p0[0], p0[C], p0[(int64_t)W * C], p0[(int64_t)W * C + C]};
+            int am = 0;
+            float best = v[0];
+#pragma unroll
+            for (int e = 1; e < 4; ++e)
+                if (v[e] > best) { best = v[e]; am = e; }
+            const int me = (iy & 1) * 2 + (ix & 1);
+            if (me == am) g = dout[(((int64_t)b * Ho + oy) * Wo + ox) * C + c];
+        }
+        dx[idx] = g;
+    }
+}
+extern "C" int tg_maxpool2_bwd(const float* dout, const float* x, int B, int H, int W, int C, float* dx, tg_stream_t stream) {
+    TG_REQUIRE(dout && x && dx && B > 0 && H > 1 && W > 1 && C > 0, "tg_maxpool2_bwd: bad arguments");
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid((int64_t)B * H * W * C, 256)), dim3(256), 0, S(stream), dout, x, B, H, W,
+                       C, dx);
+    TG_CHECK_LAUNCH("maxpool2_bwd_kernel");
+    return TG_OK;
+}
+
+// =================================================================================================
+// scalar reductions: per-block fp64 partials -> one finalize thread block
+// =================================================================================================
+template <int NQ>
+__device__ __forceinline__ void block_reduce_store(double (&q)[NQ], double* __restrict__ partial) {
+    __shared__ double red[NQ][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        double v = wave_sum_d(q[i]);
+        if (lane == 0) red[i][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) partial[(size_t)blockIdx.x * NQ + i] = red[i][0] + red[i][1] + red[i][2] + red[i][3];
+    }
+}
+static int red_grid(int64_t n) {
+    int64_t g = cdiv64(n, 256 * 8);
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+extern "C" size_t tg_reduce_ws_bytes(int64_t n) { return (size_t)(red_grid(n) * 8 + 16) * sizeof(double); }
+extern "C" size_t tg_pixel_loss_ws_bytes(int B, int H, int W) { return tg_reduce_ws_bytes((int64_t)B * H * W); }
+
+// ---- pixel-space losses -------------------------------------------------------------------------------
+__device__ __forceinline__ float band_at(const float* __restrict__ m, int b, int y, int x, int H, int W) {
+    float mx = -INFINITY, mn = INFINITY;
+    for (int dy = -1; dy <= 1; ++dy) {
+        int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+            int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            float v = m[((int64_t)b * H + yy) * W + xx];
+            mx = fmaxf(mx, v);
+            mn = fminf(mn, v);
+        }
+    }
+    // dilated - eroded, eroded = 1 - maxpool(1 - m) = min(m) over the window (losses.py:406-408)
+    float d = mx - (1.f - (1.f - mn));
+    return fminf(fmaxf(d, 0.f), 1.f);
+}
+
+__global__ __launch_bounds__(256) void pixel_loss_sums_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                              const float* __restrict__ m, const float* __restrict__ l1w,
+                                                              int B, int H, int W, double* __restrict__ partial) {
+    const int64_t total = (int64_t)B * H * W;
+    double q[5] = {0, 0, 0, 0, 0};
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int x = (int)(idx % W);
+        const int64_t tt = idx / W;
+        const int y = (int)(tt % H);
+        const int b = (int)(tt / H);
+        const float ad = fabsf(p[idx] - t[idx]);
+        q[0] += (double)(l1w ? ad * l1w[idx] : ad);
+        const float xh = p[idx] * (1.f - m[idx]);
+        if (y > 0) {
+            float d = xh - p[idx - W] * (1.f - m[idx - W]);
+            q[1] += (double)(d * d);
+        }
+        if (x > 0) {
+            float d = xh - p[idx - 1] * (1.f - m[idx - 1]);
+            q[2] += (double)(d * d);
+        }
+        const float bd = band_at(m, b, y, x, H, W);
+        q[3] += (double)(ad * bd);
+        q[4] += (double)bd;
+    }
+    block_reduce_store<5>(q, partial);
+}
+// out5 = {l1, tv, boundary, sum(band), total}; coef[0..3] = per-element gradient coefficients
+__global__ void pixel_loss_final_kernel(const double* __restrict__ partial, int nblocks, int B, int H, int W, float w_l1,
+                                        float w_tv, float w_bnd, float eps, const float* __restrict__ gscale,
+                                        float* __restrict__ out5, float* __restrict__ coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < nblocks; ++b)
+        for (int i = 0; i < 5; ++i) s[i] += partial[(size_t)b * 5 + i];
+    const double n = (double)B * H * W;
+    const double count_h = (double)B * (H - 1) * W, count_w = (double)B * H * (W - 1);
+    const float l1 = (float)(s[0] / n);
+    const float h_tv = (float)s[1], w_tv_sum = (float)s[2];
+    // losses.py:127: 2 * (h_tv / count_h + w_tv / count_w) / batch_size
+    const float tv = 2.f * (h_tv / (float)count_h + w_tv_sum / (float)count_w) / (float)B;
+    const float den = (float)s[4];
+    float bnd = 0.f;
+    bool bnd_on = den >= 1.0f;
+    if (bnd_on) {
+        bnd = (float)s[3] / (den + eps);
+        if (isnan(bnd) || isinf(bnd)) { bnd = 0.f; bnd_on = false; }
+    }
+    out5[0] = l1;
+    out5[1] = tv;
+    out5[2] = bnd;
+    out5[3] = den;
+    out5[4] = w_l1 * l1 + w_tv * tv + w_bnd * bnd;
+    const float gs = gscale ? *gscale : 1.f;
+    coef[0] = gs * w_l1 / (float)n;
+    coef[1] = gs * w_tv * 2.f / ((float)B * (float)count_h) * 2.f;   // d/dx of d^2 carries the second 2
+    coef[2] = gs * w_tv * 2.f / ((float)B * (float)count_w) * 2.f;
+    coef[3] = bnd_on ? gs * w_bnd / (den + eps) : 0.f;
+}
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) - (v < 0.f); }
+__global__ __launch_bounds__(256) void pixel_loss_grad_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                              const float* __restrict__ m, const float* __restrict__ l1w,
+                                                              int B, int H, int W, const float* __restrict__ coef,
+                                                              int accumulate, float* __restrict__ dp) {
+    const int64_t total = (int64_t)B * H * W;
+    const float c_l1 = coef[0], c_h = coef[1], c_w = coef[2], c_b = coef[3];
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int x = (int)(idx % W);
+        const int64_t tt = idx / W;
+        const int y = (int)(tt % H);
+        const int b = (int)(tt / H);
+        const float s = sgn(p[idx] - t[idx]);
+        float g = c_l1 * s * (l1w ? l1w[idx] : 1.f);
+        const float hm = 1.f - m[idx];
+        const float xh = p[idx] * hm;
+        float dh = 0.f, dw = 0.f;
+        if (y > 0) dh += xh - p[idx - W] * (1.f - m[idx - W]);
+        if (y < H - 1) dh -= p[idx + W] * (1.f - m[idx + W]) - xh;
+        if (x > 0) dw += xh - p[idx - 1] * (1.f - m[idx - 1]);
+        if (x < W - 1) dw -= p[idx + 1] * (1.f - m[idx + 1]) - xh;
+        g += hm * (c_h * dh + c_w * dw);
+        if (c_b != 0.f) g += c_b * s * band_at(m, b, y, x, H, W);
+        dp[idx] = accumulate ? dp[idx] + g : g;
+    }
+}
+extern "C" int tg_pixel_losses(const float* pred, const float* target, const float* mask, const float* l1_weight, int B,
+                               int H, int W, float w_l1, float w_tv, float w_bnd, float bnd_eps, const float* gscale,
+                               float* out5, float* dpred, int accumulate, float* ws, size_t ws_bytes, tg_stream_t stream) {
+    TG_REQUIRE(pred && target && mask && out5 && ws, "tg_pixel_losses: null pointer");
+    TG_REQUIRE(B > 0 && H > 1 && W > 1, "tg_pixel_losses: bad dims");
+    TG_REQUIRE(ws_bytes >= tg_pixel_loss_ws_bytes(B, H, W), "tg_pixel_losses: workspace too small");
+    const int64_t n = (int64_t)B * H * W;
+    const int grid = red_grid(n);
+    double* partial = reinterpret_cast<double*>(ws);
+    float* coef = reinterpret_cast<float*>(partial + (size_t)grid * 8);
+    hipLaunchKernelGGL(pixel_loss_sums_kernel, dim3(grid), dim3(256), 0, S(stream), pred, target, mask, l1_weight, B, H, W,
+                       partial);
+    TG_CHECK_LAUNCH("pixel_loss_sums_kernel");
+    hipLaunchKernelGGL(pixel_loss_final_kernel, dim3(1), dim3(64), 0, S(stream), partial, grid, B, H, W, w_l1, w_tv, w_bnd,
+                       bnd_eps, gscale, out5, coef);
+    TG_CHECK_LAUNCH("pixel_loss_final_kernel");
+    if (dpred) {
+        hipLaunchKernelGGL(pixel_loss_grad_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), pred, target, mask, l1_weight,
+                           B, H, W, coef, accumulate, dpred);
+        TG_CHECK_LAUNCH("pixel_loss_grad_kernel");
+    }
+    return TG_OK;
+}
+// ---- mean |a-b| (+ gradient) -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l1_mean_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                      float coef, const float* __restrict__ gscale, float* __restrict__ da,
+                                                      double* __restrict__ partial) {
+    double q[1] = {0};
+    const float k = da ? coef * (gscale ? *gscale : 1.f) / (float)n : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = a[i] - b[i];
+        q[0] += (double)fabsf(d);
+        if (da) da[i] = k * sgn(d);
+    }
+    block_reduce_store<1>(q, partial);
+}
+__global__ void mean_final_kernel(const double* __restrict__ partial, int nblocks, double inv_n, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0;
+    for (int b = 0; b < nblocks; ++b) s += partial[b];
+    out[0] = (float)(s * inv_n);
+}
+extern "C" int tg_l1_mean(const float* a, const float* b, int64_t n, float coef, const float* gscale, float* out1, float* da,
+                          float* ws, size_t ws_bytes, tg_stream_t stream) {
+    TG_REQUIRE(a && b && out1 && ws && n > 0, "tg_l1_mean: bad arguments");
+    TG_REQUIRE(ws_bytes >= tg_reduce_ws_bytes(n), "tg_l1_mean: workspace too small");
+    const int grid = red_grid(n);
+    double* partial = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(l1_mean_kernel, dim3(grid), dim3(256), 0, S(stream), a, b, n, coef, gscale, da, partial);
+    TG_CHECK_LAUNCH("l1_mean_kernel");
+    hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(64), 0, S(stream), partial, grid, 1.0 / (double)n, out1);
+    TG_CHECK_LAUNCH("mean_final_kernel");
+    return TG_OK;
+}
+
+// ---- BCE with logits, constant target -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ z, int64_t n, float target, float coef,
+                                                  const float* __restrict__ gscale, float* __restrict__ dz,
+                                                  double* __restrict__ partial) {
+    double q[1] = {0};
+    const float k = dz ? coef * (gscale ? *gscale : 1.f) / (float)n : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float x = z[i];
+        // ATen: (1 - t) * x + max(-x, 0) + log(exp(-max) + exp(-x - max))  ==  max(x,0) - x*t + log1p(exp(-|x|))
+        const float loss = fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x)));
+        q[0] += (double)loss;
+        if (dz) dz[i] = k * (sigmoidf_(x) - target);
+    }
+    block_reduce_store<1>(q, partial);
+}
+extern "C" int tg_bce_logits(const float* z, int64_t n, float target, float coef, const float* gscale, float* out1, float* dz,
+                             float* ws, size_t ws_bytes, tg_stream_t stream) {
+    TG_REQUIRE(z && out1 && ws && n > 0, "tg_bce_logits: bad arguments");
+    TG_REQUIRE(ws_bytes >= tg_reduce_ws_bytes(n), "tg_bce_logits: workspace too small");
+    const int grid = red_grid(n);
+    double* partial = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(bce_kernel, dim3(grid), dim3(256), 0, S(stream), z, n, target, coef, gscale, dz, partial);
+    TG_CHECK_LAUNCH("bce_kernel");
+    hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(64), 0, S(stream), partial, grid, 1.0 / (double)n, out1);
+    TG_CHECK_LAUNCH("mean_final_kernel");
+    return TG_OK;
+}
+
+// =================================================================================================
+// Adam, axpby, lincomb, layout transposes
+// =================================================================================================
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float one_minus_b1, float b2,
+                                                   float one_minus_b2, float step_size, float inv_bc2_sqrt, float eps,
+                                                   float grad_scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gr = g[i] * grad_scale;
+        const float mi = m[i] + one_minus_b1 * (gr - m[i]);       // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + one_minus_b2 * gr * gr;      // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+extern "C" int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                       int step, float grad_scale, tg_stream_t stream) {
+    TG_REQUIRE(p && g && m && v && n > 0 && step >= 1, "tg_adam: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), p, g, m, v, n, 1.f - beta1, beta2,
+                       1.f - beta2, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps, grad_scale);
+    TG_CHECK_LAUNCH("adam_kernel");
+    return TG_OK;
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, float a, float b, float* __restrict__ y,
+                                                    int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = b == 0.f ? a * x[i] : a * x[i] + b * y[i];
+}
+extern "C" int tg_axpby(const float* x, float a, float b, float* y, int64_t n, tg_stream_t stream) {
+    TG_REQUIRE(x && y && n > 0, "tg_axpby: bad arguments");
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), x, a, b, y, n);
+    TG_CHECK_LAUNCH("axpby_kernel");
+    return TG_OK;
+}
+__global__ __launch_bounds__(256) void lincomb_kernel(const float* __restrict__ x, float a, const float* __restrict__ y, float b,
+                                                      float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = a * x[i] + b * y[i];
+}
+extern "C" int tg_lincomb(const float* x, float a, const float* y, float b, float* out, int64_t n, tg_stream_t stream) {
+    TG_REQUIRE(x && y && out && n > 0, "tg_lincomb: bad arguments");
+    hipLaunchKernelGGL(lincomb_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), x, a, y, b, out, n);
+    TG_CHECK_LAUNCH("lincomb_kernel");
+    return TG_OK;
+}
+
+__global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                  int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a[i] * b[i];
+}
+extern "C" int tg_mul(const float* a, const float* b, float* out, int64_t n, tg_stream_t stream) {
+    TG_REQUIRE(a && b && out && n > 0, "tg_mul: bad arguments");
+    hipLaunchKernelGGL(mul_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), a, b, out, n);
+    TG_CHECK_LAUNCH("mul_kernel");
+    return TG_OK;
+}
+
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                double n, int C, float eps, float momentum,
+                                                                float* __restrict__ rm, float* __restrict__ rv,
+                                                                int64_t* __restrict__ nbt) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    const double r = (double)rstd[c];
+    double var = 1.0 / (r * r) - (double)eps;
+    if (var < 0.0) var = 0.0;
+    rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * (double)mean[c]);
+    rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * var * (n / (n - 1.0)));
+}
+extern "C" int tg_bn_running_update(const float* save_mean, const float* save_rstd, int64_t rows, int C, float eps,
+                                    float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                    tg_stream_t stream) {
+    TG_REQUIRE(save_mean && save_rstd && running_mean && running_var && rows > 1 && C > 0, "tg_bn_running_update: bad arguments");
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), save_mean, save_rstd, (double)rows,
+                       C, eps, momentum, running_mean, running_var, num_batches_tracked);
+    TG_CHECK_LAUNCH("bn_running_update_kernel");
+    return TG_OK;
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, int B, int C, int HW,
+                                                           float* __restrict__ y) {
+    const int64_t total = (int64_t)B * C * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t t = i / C;
+        const int64_t hw = t % HW, b = t / HW;
+        y[i] = x[(b * C + c) * HW + hw];
+    }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, int B, int C, int HW,
+                                                           float* __restrict__ y) {
+    const int64_t total = (int64_t)B * C * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t hw = i % HW;
+        const int64_t t = i / HW;
+        const int c = (int)(t % C);
+        const int64_t b = t / C;
+        y[i] = x[(b * HW + hw) * C + c];
+    }
+}
+extern "C" int tg_nchw_to_nhwc(const float* x, int B, int C, int H, int W, float* y, tg_stream_t stream) {
+    TG_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, "tg_nchw_to_nhwc: bad arguments");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid((int64_t)B * C * H * W, 256)), dim3(256), 0, S(stream), x, B, C, H * W, y);
+    TG_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+    return TG_OK;
+}
+extern "C" int tg_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, tg_stream_t stream) {
+    TG_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, "tg_nhwc_to_nchw: bad arguments");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid((int64_t)B * C * H * W, 256)), dim3(256), 0, S(stream), x, B, C, H * W, y);
+    TG_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+    return TG_OK;
+}

@@ -1,0 +1,224 @@
+"""InpaintingLoss / HumanGuidedLoss / BoundaryAwareLoss on MI355X.
+
+Same class names, constructor signatures, `forward` signatures and touched attributes
+(`boundary_loss`, `boundary_weight`, `vgg_layers`, `l1_loss`, `perceptual_weight`, `tv_weight`) as
+/root/reference/mvp_gan/src/utils/losses.py:10-204,206-428.  The arithmetic is HIP:
+  * L1 + total-variation + boundary-aware terms: one fused reduction family (tg_pixel_losses), no
+    host synchronisation (the reference syncs three times per call, losses.py:111,411,419);
+  * perceptual term: VGG16 features[:16] on the tg_conv_* kernels, prediction and target batched,
+    first conv folded 3->1 input channel (the three channels are identical, losses.py:79-80);
+  * the reference's blanket try/except fallbacks (losses.py:91-93,101-103,112-114,425-428) are
+    deliberately NOT reproduced: a kernel error raises.
+
+VGG weights: torchvision and the ImageNet checkpoint are not available offline.  Resolution order:
+`vgg_weights` argument / $TERRAGAN_VGG16_WEIGHTS (a local torchvision vgg16 state-dict, keys
+`features.N.*` or `N.*`), then torchvision if importable, else a deterministic stand-in drawn with
+nn.Conv2d's default init for all 13 VGG16 convs (same RNG consumption as building the torchvision
+model), with a warning.
+"""
+import logging
+import os
+
+import torch
+import torch.nn as nn
+
+from tg_hip import engine as E
+from tg_hip import ops as O
+
+from ..models._common import as_bhw, require_hip
+
+logger = logging.getLogger(__name__)
+
+_VGG16_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+
+
+def _vgg16_features_16(vgg_weights=None):
+    path = vgg_weights or os.environ.get("TERRAGAN_VGG16_WEIGHTS")
+    sd = None
+    if path is None:
+        try:  # pragma: no cover - torchvision is absent in the build image
+            from torchvision.models import VGG16_Weights, vgg16
+            return vgg16(weights=VGG16_Weights.IMAGENET1K_V1).features[:16]
+        except Exception:  # noqa: BLE001
+            logger.warning("torchvision / ImageNet VGG16 weights unavailable: using a deterministic stand-in "
+                           "trunk (set TERRAGAN_VGG16_WEIGHTS to a local vgg16 state-dict for real weights)")
+    else:
+        sd = torch.load(path, map_location="cpu")
+        sd = {k[len("features."):] if k.startswith("features.") else k: v for k, v in sd.items()}
+    layers, cin = [], 3
+    for v in _VGG16_CFG:
+        if v == "M":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    feats = nn.Sequential(*layers)[:16]
+    if sd is not None:
+        feats.load_state_dict({k: v for k, v in sd.items() if k.split(".")[0].isdigit() and int(k.split(".")[0]) < 16})
+    return feats
+
+
+class _L1Mean(nn.Module):
+    """nn.L1Loss() stand-in (mean |a-b|) on the tg_l1_mean kernel; differentiable w.r.t. `a`."""
+
+    def forward(self, a, b):
+        return _L1Fn.apply(a, b)
+
+
+class _L1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        require_hip(a, "L1")
+        ac, bc = a.detach().float().contiguous(), b.detach().float().contiguous()
+        out, _ = O.l1_mean(ac, bc, want_grad=False)
+        ctx.save_for_backward(ac, bc)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ac, bc = ctx.saved_tensors
+        _, da = O.l1_mean(ac, bc, 1.0, gscale=g.float().contiguous().reshape(1), want_grad=True)
+        return da, None
+
+
+class BoundaryAwareLoss(nn.Module):
+    """Effective reference behaviour (losses.py:386-428): L1 over the 3x3 morphological-gradient
+    band of the mask, 0 when the band is empty.  `boundary_width` and the Sobel/gradient helpers of
+    the reference (losses.py:215-384) never reach `forward` and are not reproduced."""
+
+    def __init__(self, boundary_width: int = 10, epsilon: float = 1e-6, device=None):
+        super().__init__()
+        self.boundary_width, self.epsilon = boundary_width, epsilon
+        self.device = device if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+    def forward(self, pred, target, mask):
+        return _PixelLossFn.apply(pred, target, mask, None, 0.0, 0.0, 1.0, self.epsilon)
+
+
+class _PixelLossFn(torch.autograd.Function):
+    """w_l1*L1(+weight) + w_tv*TV(pred*(1-mask)) + w_bnd*Boundary as one node."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask, l1_weight, w_l1, w_tv, w_bnd, eps):
+        require_hip(pred, "pixel losses")
+        p, t, m = as_bhw(pred, "loss"), as_bhw(target, "loss"), as_bhw(mask, "loss")
+        lw = as_bhw(l1_weight, "loss") if l1_weight is not None else None
+        out5, _ = O.pixel_losses(p, t, m, w_l1, w_tv, w_bnd, l1_weight=lw, want_grad=False, eps=eps)
+        ctx.args = (p, t, m, lw, w_l1, w_tv, w_bnd, eps)
+        ctx.shape = pred.shape
+        return out5[4].reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t, m, lw, w_l1, w_tv, w_bnd, eps = ctx.args
+        _, dp = O.pixel_losses(p, t, m, w_l1, w_tv, w_bnd, l1_weight=lw, gscale=g.float().contiguous().reshape(1),
+                               want_grad=True, eps=eps)
+        return dp.reshape(ctx.shape), None, None, None, None, None, None, None
+
+
+def criterion_forward(crit, pred, target, mask, want_grad, gscale=None, l1_weight=None, w_l1=1.0, scale=1.0):
+    """Fused value(+gradient) of InpaintingLoss on [B][H][W] tensors.
+    Returns (total 1-elem tensor, parts dict of 1-elem tensors, dpred or None).  `scale` multiplies
+    the whole loss (HumanGuidedLoss's base_loss_weight)."""
+    w_p, w_tv, w_b = crit.perceptual_weight, crit.tv_weight, crit.boundary_weight
+    out5, dp = O.pixel_losses(pred, target, mask, w_l1 * scale, max(w_tv, 0.0) * scale, max(w_b, 0.0) * scale,
+                              l1_weight=l1_weight, gscale=gscale, want_grad=want_grad, eps=crit.boundary_loss.epsilon)
+    total = out5[4:5]
+    parts = {"pixel": out5}
+    if w_p > 0:
+        V = crit._vgg_tensors()
+        B = pred.shape[0]
+        both = torch.empty((2 * B,) + tuple(pred.shape[1:]), dtype=pred.dtype, device=pred.device)
+        both[:B].copy_(pred)            # device-to-device memcpy (plumbing)
+        both[B:].copy_(target)
+        feats, vctx = E.vgg_forward(V, both, keep=want_grad)
+        fp, ft = feats[:B], feats[B:]
+        perc, dfeat = O.l1_mean(fp, ft, w_p * scale, gscale=gscale, want_grad=want_grad)
+        parts["perc"] = perc
+        total = O.lincomb(total, 1.0, perc, w_p * scale)
+        if want_grad:
+            dperc = E.vgg_backward(vctx, dfeat, nb=B)
+            O.axpby_(dperc, 1.0, 1.0, dp)
+    return total, parts, dp
+
+
+class _InpaintingLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, mask, crit):
+        require_hip(pred, "InpaintingLoss")
+        p, t, m = as_bhw(pred, "InpaintingLoss"), as_bhw(target, "InpaintingLoss"), as_bhw(mask, "InpaintingLoss")
+        total, _parts, _ = criterion_forward(crit, p, t, m, want_grad=False)
+        ctx.args, ctx.crit, ctx.shape = (p, t, m), crit, pred.shape
+        return total.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t, m = ctx.args
+        _t, _parts, dp = criterion_forward(ctx.crit, p, t, m, want_grad=True, gscale=g.float().contiguous().reshape(1))
+        return dp.reshape(ctx.shape), None, None, None
+
+
+class InpaintingLoss(nn.Module):
+    def __init__(self, perceptual_weight: float = 0.1, tv_weight: float = 0.1, boundary_weight: float = 0.5,
+                 device=None, vgg_weights=None):
+        super().__init__()
+        self.device = device if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.l1_loss = _L1Mean()
+        self.perceptual_weight, self.tv_weight, self.boundary_weight = perceptual_weight, tv_weight, boundary_weight
+        self.vgg_layers = _vgg16_features_16(vgg_weights).eval().to(self.device)
+        for p in self.vgg_layers.parameters():
+            p.requires_grad = False
+        self.boundary_loss = BoundaryAwareLoss(device=self.device).to(self.device)
+        self._vgg_cache = None
+
+    def to(self, device):
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        self.boundary_loss.device = self.device
+        self._vgg_cache = None
+        return super().to(device)
+
+    def _apply(self, fn, *a, **kw):
+        self._vgg_cache = None
+        return super()._apply(fn, *a, **kw)
+
+    def _vgg_tensors(self):
+        """Frozen trunk tensors for the engine, incl. the 3->1 folded first kernel (cached per storage)."""
+        key = tuple((p.data_ptr(), p._version) for p in self.vgg_layers.parameters())
+        if self._vgg_cache is None or self._vgg_cache[0] != key:
+            V = {k: v.detach() for k, v in self.vgg_layers.state_dict().items()}
+            for k in list(V):
+                if k.endswith(".weight"):
+                    V[k] = O.weight_view(V[k]).permute(0, 3, 1, 2)
+            V["0.folded"] = O.fold_cin(V["0.weight"])
+            self._vgg_cache = (key, V)
+        return self._vgg_cache[1]
+
+    def forward(self, input, target, mask):
+        return _InpaintingLossFn.apply(input.to(self.device), target.to(self.device), mask.to(self.device), self)
+
+    def total_variation_loss(self, x):
+        """losses.py:118-127 (B divided twice, as the reference)."""
+        z = torch.zeros_like(x)
+        return _PixelLossFn.apply(x, x, z, None, 0.0, 1.0, 0.0, 1e-6)
+
+
+class HumanGuidedLoss(InpaintingLoss):
+    def __init__(self, config, device=None, **kwargs):
+        kwargs.pop("device", None)
+        boundary_weight = config["training"].get("loss_weights", {}).get("boundary", 0.5)
+        super().__init__(device=device, boundary_weight=boundary_weight, **kwargs)
+        hg = config["training"]["modes"]["human_guided"]
+        self.human_feedback_weight, self.base_loss_weight = hg["human_feedback_weight"], hg["base_loss_weight"]
+
+    def forward(self, input, target, mask, human_feedback=None):
+        """losses.py:152-204: base_w * InpaintingLoss + human_w * [L1(p*h, t*h) + w_b * Boundary(p, t, h)]
+        with h = [human_mask > 0].  An all-zero h gives exactly 0 for both human terms, which is what the
+        reference's host-synchronising `if h.sum() > 0` guard (losses.py:171) returns."""
+        base = super().forward(input, target, mask)
+        total = self.base_loss_weight * base
+        if human_feedback is not None and human_feedback.get("mask") is not None:
+            h = (human_feedback["mask"].to(self.device) > 0).float()
+            human = _PixelLossFn.apply(input.to(self.device), target.to(self.device), h, h, 1.0, 0.0,
+                                       max(self.boundary_weight, 0.0), self.boundary_loss.epsilon)
+            total = total + self.human_feedback_weight * human
+        return total

@@ -1,0 +1,219 @@
+"""Explicit forward/backward schedules of the hot path on the HIP kernels (no autograd inside).
+
+Each engine function takes the module's tensors as a dict keyed like the reference state-dict
+(`enc1.input_conv.weight`, `model.3.running_mean`, ...) and returns a context object that the
+matching backward consumes.  Activations are [B][H][W][C]; 1-channel images/masks are [B][H][W].
+
+Reference arithmetic reproduced (paths relative to /root/reference):
+  generator_*      mvp_gan/src/models/generator.py:31-84 + pconv.py:25-50
+  discriminator_*  mvp_gan/src/models/discriminator.py:17-26
+  vgg_*            torchvision vgg16.features[:16] as used by mvp_gan/src/utils/losses.py:31-34,79-90
+"""
+from types import SimpleNamespace as NS
+
+from . import ops as O
+
+# (name, cin, cout, k, stride, pad) -- generator.py:13-28
+G_ENC = [("enc1", 1, 64, 7, 2, 3), ("enc2", 64, 128, 5, 2, 2), ("enc3", 128, 256, 5, 2, 2),
+         ("enc4", 256, 512, 3, 2, 1), ("enc5", 512, 512, 3, 2, 1), ("enc6", 512, 512, 3, 2, 1),
+         ("enc7", 512, 512, 3, 2, 1)]
+G_DEC = [("dec7", 1024, 512, 3, 1, 1), ("dec6", 1024, 512, 3, 1, 1), ("dec5", 1024, 512, 3, 1, 1),
+         ("dec4", 768, 256, 3, 1, 1), ("dec3", 384, 128, 3, 1, 1), ("dec2", 192, 64, 3, 1, 1),
+         ("dec1", 64, 64, 3, 1, 1)]
+# (conv index, bn index or None, cin, cout, k, stride, pad, leaky) -- discriminator.py:17-23
+D_LAYERS = [(0, None, None, 64, 4, 2, 1, True), (2, 3, 64, 128, 4, 2, 1, True), (5, 6, 128, 256, 4, 2, 1, True),
+            (8, 9, 256, 512, 4, 2, 1, True), (11, None, 512, 1, 4, 1, 1, False)]
+# features[:16]: conv indices, 'M' = 2x2 max-pool; every conv is followed by ReLU
+VGG_TRUNK = [0, 2, "M", 5, 7, "M", 10, 12, 14]
+
+
+# --------------------------------------------------------------------------------------------------
+# partial-conv layer (conv -> *ratio -> BN -> ReLU)
+# --------------------------------------------------------------------------------------------------
+def _pconv_fwd(P, name, k, s, p, x, in_mask, ratio, training):
+    y = O.conv_fwd(x, P[f"{name}.input_conv.weight"], P[f"{name}.input_conv.bias"].detach(), k, s, p,
+                   in_mask=in_mask, ratio=ratio)
+    if training:
+        mean, rstd = O.bn_stats(y, P[f"{name}.bn.running_mean"], P[f"{name}.bn.running_var"],
+                                P[f"{name}.bn.num_batches_tracked"])
+    else:
+        mean, rstd = O.bn_eval_stats(P[f"{name}.bn.running_mean"], P[f"{name}.bn.running_var"])
+    a = O.bn_act_fwd(y, mean, rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU)
+    return a, NS(name=name, k=k, s=s, p=p, x=x, in_mask=in_mask, ratio=ratio, y=y, mean=mean, rstd=rstd)
+
+
+def _pconv_bwd(P, c, da, grads, dx_out=None, want_dx=True):
+    """da: grad w.r.t. the layer's ReLU output (consumed in place).  Returns dx (or None)."""
+    name = c.name
+    dyr, dgamma, dbeta = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU,
+                                      ratio=c.ratio)
+    dw, db = O.conv_wgrad(c.x, dyr, P[f"{name}.input_conv.weight"], c.k, c.s, c.p, in_mask=c.in_mask)
+    grads[f"{name}.input_conv.weight"], grads[f"{name}.input_conv.bias"] = dw, db
+    grads[f"{name}.bn.weight"], grads[f"{name}.bn.bias"] = dgamma, dbeta
+    if not want_dx:
+        return None
+    return O.conv_dgrad(dyr, P[f"{name}.input_conv.weight"], tuple(c.x.shape), c.k, c.s, c.p, in_mask=c.in_mask, out=dx_out)
+
+
+# --------------------------------------------------------------------------------------------------
+# generator
+# --------------------------------------------------------------------------------------------------
+def generator_forward(P, x, mask, training=True):
+    """x (already masked image) and mask: [B][H][W].  Returns (out [B][H][W], ctx)."""
+    B, H, W = x.shape
+    # mask pyramid first: it depends on the input mask only (pconv.py:33-40, generator.py:51-54,68,74)
+    m, er = [mask], [None]
+    for (_n, _ci, _co, k, s, p) in G_ENC:
+        mo, r = O.mask_update(m[-1], k, s, p)
+        m.append(mo)
+        er.append(r)
+    dm, dmasks, dr = m[7], [], []
+    for i, (_n, _ci, _co, k, s, p) in enumerate(G_DEC):
+        skip_m = m[6 - i] if i < 6 else mask
+        mm = O.mask_up_merge(dm, skip_m)
+        dm, r = O.mask_update(mm, k, s, p)
+        dmasks.append(mm)
+        dr.append(r)
+
+    enc_ctx, e = [], [x.reshape(B, H, W, 1)]
+    for i, (name, _ci, _co, k, s, p) in enumerate(G_ENC):
+        a, c = _pconv_fwd(P, name, k, s, p, e[-1], m[i], er[i + 1], training)
+        e.append(a)
+        enc_ctx.append(c)
+    d, dec_ctx = e[7], []
+    for i, (name, _ci, _co, k, s, p) in enumerate(G_DEC):
+        skip = e[6 - i] if i < 6 else None
+        Hs, Ws = (skip.shape[1], skip.shape[2]) if skip is not None else (H, W)
+        up_shape = tuple(d.shape)
+        cat = O.upcat_fwd(d, skip, Hs, Ws)
+        d, c = _pconv_fwd(P, name, k, s, p, cat, dmasks[i], dr[i], training)
+        c.up_shape = up_shape
+        dec_ctx.append(c)
+    logits = O.conv_fwd(d, P["final.weight"], P["final.bias"].detach(), 3, 1, 1)      # generator.py:29,56
+    out = O.sigmoid_composite_fwd(logits.reshape(B, H, W), x, mask)                     # generator.py:57-62
+    return out, NS(enc=enc_ctx, dec=dec_ctx, d0=d, logits=logits, mask=mask, shape=(B, H, W))
+
+
+def generator_backward(P, ctx, dout, want_dx=False):
+    """dout: [B][H][W].  Returns (grads dict keyed like the state-dict, dx or None)."""
+    B, H, W = ctx.shape
+    grads = {}
+    dz, dx_comp = O.sigmoid_composite_bwd(dout, ctx.logits.reshape(B, H, W), ctx.mask, want_dx)
+    dz = dz.reshape(B, H, W, 1)
+    grads["final.weight"], grads["final.bias"] = O.conv_wgrad(ctx.d0, dz, P["final.weight"], 3, 1, 1)
+    da = O.conv_dgrad(dz, P["final.weight"], tuple(ctx.d0.shape), 3, 1, 1)
+    dskips = {}
+    for i in range(6, -1, -1):                     # dec1 ... dec7
+        c = ctx.dec[i]
+        dcat = _pconv_bwd(P, c, da, grads)
+        _b, h, w, Cu = c.up_shape
+        da, dskip = O.upcat_bwd(dcat, h, w, Cu)
+        if i < 6:
+            dskips[6 - i] = dskip                  # gradient reaching encoder output e[6-i] through the skip
+    # da is now the gradient of e7 (through dec7's upsample path only)
+    dx = None
+    for i in range(6, -1, -1):                     # enc7 ... enc1
+        c = ctx.enc[i]
+        if i > 0:
+            # gradient of e[i] = skip part (already there) + this layer's dgrad, accumulated in place
+            da = _pconv_bwd(P, c, da, grads, dx_out=dskips[i])
+        else:
+            dx = _pconv_bwd(P, c, da, grads, want_dx=want_dx)
+    if want_dx:
+        dx = O.axpby_(dx_comp, 1.0, 1.0, dx.reshape(B, H, W))
+    return grads, dx
+
+
+# --------------------------------------------------------------------------------------------------
+# discriminator
+# --------------------------------------------------------------------------------------------------
+def discriminator_forward(P, img, training=True):
+    """img [B][H][W] (1 channel) or [B][H][W][C].  Returns (logits [B][h][w][1], ctx)."""
+    h = img if img.dim() == 4 else img.reshape(*img.shape, 1)
+    layers = []
+    for (ci, bi, _cin, _cout, k, s, p, leaky) in D_LAYERS:
+        w, b = P[f"model.{ci}.weight"], P[f"model.{ci}.bias"].detach()
+        if bi is None:
+            act = O.ACT_LEAKY if leaky else O.ACT_NONE
+            a = O.conv_fwd(h, w, b, k, s, p, act=act, slope=0.2)
+            layers.append(NS(ci=ci, bi=None, k=k, s=s, p=p, x=h, a=a, act=act))
+        else:
+            y = O.conv_fwd(h, w, b, k, s, p)
+            if training:
+                mean, rstd = O.bn_stats(y, P[f"model.{bi}.running_mean"], P[f"model.{bi}.running_var"],
+                                        P[f"model.{bi}.num_batches_tracked"])
+            else:
+                mean, rstd = O.bn_eval_stats(P[f"model.{bi}.running_mean"], P[f"model.{bi}.running_var"])
+            a = O.bn_act_fwd(y, mean, rstd, P[f"model.{bi}.weight"], P[f"model.{bi}.bias"], O.ACT_LEAKY, 0.2)
+            layers.append(NS(ci=ci, bi=bi, k=k, s=s, p=p, x=h, y=y, mean=mean, rstd=rstd, a=a))
+        h = a
+    return h, NS(layers=layers)
+
+
+def discriminator_backward(P, ctx, dlogits, want_wgrad=True, want_dimg=False):
+    """Returns (grads dict, dimg [B][H][W][C] or None).  want_wgrad=False skips the parameter
+    gradients the reference computes and then discards in the generator step (train.py:204,210)."""
+    grads, da = {}, dlogits
+    for li in range(len(ctx.layers) - 1, -1, -1):
+        c = ctx.layers[li]
+        w = P[f"model.{c.ci}.weight"]
+        if c.bi is None:
+            dy = O.act_bwd(da, c.a, c.act, 0.2) if c.act != O.ACT_NONE else da
+        else:
+            dy, dgamma, dbeta = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"model.{c.bi}.weight"], P[f"model.{c.bi}.bias"],
+                                             O.ACT_LEAKY, 0.2)
+            if want_wgrad:
+                grads[f"model.{c.bi}.weight"], grads[f"model.{c.bi}.bias"] = dgamma, dbeta
+        if want_wgrad:
+            grads[f"model.{c.ci}.weight"], grads[f"model.{c.ci}.bias"] = O.conv_wgrad(c.x, dy, w, c.k, c.s, c.p)
+        if li > 0 or want_dimg:
+            da = O.conv_dgrad(dy, w, tuple(c.x.shape), c.k, c.s, c.p)
+        else:
+            da = None
+    return grads, da
+
+
+def discriminator_replay_running_stats(P, ctx):
+    """Re-apply the BN running-stat update of a forward pass whose inputs and weights are identical
+    to `ctx`'s (D(gen.detach()) after D(gen), train.py:202,212) without recomputing it."""
+    for c in ctx.layers:
+        if c.bi is not None:
+            rows = c.y.numel() // c.y.shape[-1]
+            O.bn_running_update(c.mean, c.rstd, rows, P[f"model.{c.bi}.running_mean"], P[f"model.{c.bi}.running_var"],
+                                P[f"model.{c.bi}.num_batches_tracked"])
+
+
+# --------------------------------------------------------------------------------------------------
+# frozen VGG16 trunk (features[:16]) on a 1-channel image repeated x3 (losses.py:79-90)
+# --------------------------------------------------------------------------------------------------
+def vgg_forward(V, img, keep=True):
+    """V: {'0.weight','0.bias',...,'0.folded'}; img [B][H][W].  Returns (features, ctx)."""
+    h = img.reshape(*img.shape, 1)
+    steps = []
+    for item in VGG_TRUNK:
+        if item == "M":
+            o = O.maxpool2_fwd(h)
+            if keep:
+                steps.append(NS(kind="M", x=h))
+        else:
+            w = V["0.folded"] if item == 0 else V[f"{item}.weight"]
+            o = O.conv_fwd(h, w, V[f"{item}.bias"], 3, 1, 1, act=O.ACT_RELU)
+            if keep:
+                steps.append(NS(kind="C", w=w, x_shape=tuple(h.shape), a=o))
+        h = o
+    return h, NS(steps=steps)
+
+
+def vgg_backward(ctx, dfeat, nb=None):
+    """Input gradient only (weights are frozen, losses.py:33-34) for the first `nb` samples."""
+    da = dfeat
+    for st in reversed(ctx.steps):
+        if st.kind == "M":
+            x = st.x if nb is None else st.x[:nb]
+            da = O.maxpool2_bwd(da, x)
+        else:
+            a = st.a if nb is None else st.a[:nb]
+            dy = O.act_bwd(da, a, O.ACT_RELU)
+            shp = st.x_shape if nb is None else (nb,) + tuple(st.x_shape[1:])
+            da = O.conv_dgrad(dy, st.w, shp, 3, 1, 1)
+    return da.reshape(da.shape[0], da.shape[1], da.shape[2])

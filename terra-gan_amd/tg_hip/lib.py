@@ -1,0 +1,81 @@
+"""ctypes loader for libterragan_hip.so -- one entry per declaration in include/terragan_hip.h."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libterragan_hip.so")
+
+
+class TgConv(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "k", "stride", "pad")]
+
+
+class TgError(RuntimeError):
+    pass
+
+
+P, I, I64, F, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+CP = C.POINTER(TgConv)
+
+# name -> (restype, argtypes); mirrors include/terragan_hip.h line by line
+SIGNATURES = {
+    "tg_version": (I, []),
+    "tg_last_error": (C.c_char_p, []),
+    "tg_conv_fwd_ws_bytes": (SZ, [CP]),
+    "tg_conv_fwd": (I, [CP, P, P, P, P, P, I, F, P, P, SZ, P]),
+    "tg_conv_dgrad_ws_bytes": (SZ, [CP]),
+    "tg_conv_dgrad": (I, [CP, P, P, P, P, I, P, SZ, P]),
+    "tg_conv_wgrad_ws_bytes": (SZ, [CP]),
+    "tg_conv_wgrad": (I, [CP, P, P, P, P, P, P, SZ, P]),
+    "tg_fold_cin": (I, [P, I, I, I, P, P]),
+    "tg_mask_update": (I, [P, I, I, I, I, I, I, I, I, P, P, P]),
+    "tg_mask_up_merge": (I, [P, P, I, I, I, I, I, P, P]),
+    "tg_bn_ws_bytes": (SZ, [I64, I]),
+    "tg_bn_stats": (I, [P, I64, I, F, F, P, P, P, P, P, P, SZ, P]),
+    "tg_bn_eval_stats": (I, [P, P, I, F, P, P, P]),
+    "tg_bn_act_fwd": (I, [P, I64, I, P, P, P, P, I, F, P, P]),
+    "tg_bn_act_bwd": (I, [P, P, I64, I, P, P, P, P, I, F, P, P, P, P, P, SZ, P]),
+    "tg_act_bwd": (I, [P, P, I64, I, I, F, P, P, P]),
+    "tg_upcat_fwd": (I, [P, P, I, I, I, I, I, I, I, P, P]),
+    "tg_upcat_bwd": (I, [P, I, I, I, I, I, I, I, P, P, P]),
+    "tg_sigmoid_composite_fwd": (I, [P, P, P, I64, P, P]),
+    "tg_sigmoid_composite_bwd": (I, [P, P, P, I64, P, P, P]),
+    "tg_maxpool2_fwd": (I, [P, I, I, I, I, P, P]),
+    "tg_maxpool2_bwd": (I, [P, P, I, I, I, I, P, P]),
+    "tg_pixel_loss_ws_bytes": (SZ, [I, I, I]),
+    "tg_pixel_losses": (I, [P, P, P, P, I, I, I, F, F, F, F, P, P, P, I, P, SZ, P]),
+    "tg_reduce_ws_bytes": (SZ, [I64]),
+    "tg_l1_mean": (I, [P, P, I64, F, P, P, P, P, SZ, P]),
+    "tg_bce_logits": (I, [P, I64, F, F, P, P, P, P, SZ, P]),
+    "tg_adam": (I, [P, P, P, P, I64, F, F, F, F, I, F, P]),
+    "tg_axpby": (I, [P, F, F, P, I64, P]),
+    "tg_lincomb": (I, [P, F, P, F, P, I64, P]),
+    "tg_mul": (I, [P, P, P, I64, P]),
+    "tg_bn_running_update": (I, [P, P, I64, I, F, F, P, P, P, P]),
+    "tg_prof_enable": (I, [I]),
+    "tg_prof_summary": (I, [I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "tg_nchw_to_nhwc": (I, [P, I, I, I, I, P, P]),
+    "tg_nhwc_to_nchw": (I, [P, I, I, I, I, P, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; fail loudly if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TgError(f"{LIB_PATH} is missing: build it with `python terra-gan_amd/build.py` "
+                          "(or __graft_entry__.build()); this framework has no CPU / eager fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise TgError(f"{what} failed (rc={rc}): {load().tg_last_error().decode()}")

@@ -1,0 +1,348 @@
+"""Tensor-level wrappers over the C ABI.  Tensors are fp32 HIP tensors, activations laid out
+[B][H][W][C] (contiguous), conv weights logical OIHW stored channels_last (= [Cout][kh][kw][Cin]).
+Torch is used for allocation and the stream handle only; every arithmetic op is a HIP kernel."""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+_ws = {}
+
+
+def _lib():
+    return L.load()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise L.TgError(f"{name}: expected a HIP (cuda) tensor -- there is no CPU path")
+    if t.dtype != torch.float32:
+        raise L.TgError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise L.TgError(f"{name}: expected a contiguous tensor, strides {t.stride()}")
+
+
+def workspace(nbytes):
+    """Stream-ordered scratch shared by all ops on (device, stream); grown on demand."""
+    dev = torch.cuda.current_device()
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        n = max(int(nbytes) // 4 + 64, 1 << 20)
+        buf = torch.empty(n, dtype=torch.float32, device=f"cuda:{dev}")
+        _ws[key] = buf
+    return buf
+
+
+def empty(*shape, like=None, device=None):
+    return torch.empty(*shape, dtype=torch.float32, device=like.device if like is not None else device)
+
+
+def weight_view(w):
+    """[Cout][kh][kw][Cin] view of an OIHW parameter stored channels_last; converts the storage
+    in place (once) if the parameter is not laid out that way yet."""
+    v = w.detach().permute(0, 2, 3, 1)
+    if not v.is_contiguous():
+        w.data = w.data.contiguous(memory_format=torch.channels_last)
+        v = w.detach().permute(0, 2, 3, 1)
+        if not v.is_contiguous():          # ambiguous strides (Cin == 1 or k == 1): force a dense OHWI buffer
+            dense = v.contiguous()
+            w.data = dense.permute(0, 3, 1, 2)
+            v = w.detach().permute(0, 2, 3, 1)
+    return v
+
+
+def conv_geom(x, cout, k, stride, pad):
+    B, H, W, Cin = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    return L.TgConv(B, H, W, Cin, Ho, Wo, cout, k, stride, pad)
+
+
+def conv_fwd(x, w, bias, k, stride, pad, in_mask=None, ratio=None, act=ACT_NONE, slope=0.0):
+    _chk(x, "x"); _chk(bias, "bias"); _chk(in_mask, "in_mask"); _chk(ratio, "ratio")
+    wv = weight_view(w)
+    _chk(wv, "weight")
+    g = conv_geom(x, wv.shape[0], k, stride, pad)
+    assert wv.shape == (g.Cout, k, k, g.Cin), (tuple(wv.shape), g.Cout, k, g.Cin)
+    y = empty(g.B, g.Ho, g.Wo, g.Cout, like=x)
+    lib = _lib()
+    nb = lib.tg_conv_fwd_ws_bytes(C.byref(g))
+    ws = workspace(nb)
+    L.check(lib.tg_conv_fwd(C.byref(g), _p(x), _p(in_mask), _p(wv), _p(bias), _p(ratio), act, slope, _p(y), _p(ws),
+                            ws.numel() * 4, _stream()), "tg_conv_fwd")
+    return y
+
+
+def conv_dgrad(dy, w, x_shape, k, stride, pad, in_mask=None, out=None):
+    """dx for an input of shape x_shape=[B,H,W,Cin]; accumulates into `out` when given."""
+    _chk(dy, "dy"); _chk(in_mask, "in_mask"); _chk(out, "out")
+    wv = weight_view(w)
+    B, H, W, Cin = x_shape
+    g = L.TgConv(B, H, W, Cin, dy.shape[1], dy.shape[2], dy.shape[3], k, stride, pad)
+    acc = 1 if out is not None else 0
+    dx = out if out is not None else empty(B, H, W, Cin, like=dy)
+    lib = _lib()
+    ws = workspace(lib.tg_conv_dgrad_ws_bytes(C.byref(g)))
+    L.check(lib.tg_conv_dgrad(C.byref(g), _p(dy), _p(wv), _p(in_mask), _p(dx), acc, _p(ws), ws.numel() * 4, _stream()),
+            "tg_conv_dgrad")
+    return dx
+
+
+def conv_wgrad(x, dy, w, k, stride, pad, in_mask=None, want_bias=True):
+    """Returns (dw, db): dw has the parameter's logical shape AND strides (channels_last)."""
+    _chk(x, "x"); _chk(dy, "dy"); _chk(in_mask, "in_mask")
+    wv = weight_view(w)
+    B, H, W, Cin = x.shape
+    g = L.TgConv(B, H, W, Cin, dy.shape[1], dy.shape[2], dy.shape[3], k, stride, pad)
+    dwv = torch.empty_like(wv)                       # [Cout][k][k][Cin] contiguous
+    db = empty(g.Cout, like=x) if want_bias else None
+    lib = _lib()
+    ws = workspace(lib.tg_conv_wgrad_ws_bytes(C.byref(g)))
+    L.check(lib.tg_conv_wgrad(C.byref(g), _p(x), _p(in_mask), _p(dy), _p(dwv), _p(db), _p(ws), ws.numel() * 4, _stream()),
+            "tg_conv_wgrad")
+    return dwv.permute(0, 3, 1, 2), db
+
+
+def fold_cin(w):
+    """[Cout,Cin,k,k] -> [Cout,1,k,k] channel-summed kernel (grey image repeated xCin)."""
+    wv = weight_view(w)
+    co, kh, kw, ci = wv.shape
+    out = empty(co, kh, kw, 1, like=wv)
+    L.check(_lib().tg_fold_cin(_p(wv), co, kh * kw, ci, _p(out), _stream()), "tg_fold_cin")
+    return out.permute(0, 3, 1, 2)
+
+
+def mask_update(mask, k, stride, pad):
+    _chk(mask, "mask")
+    B, H, W = mask.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    mo, ratio = empty(B, Ho, Wo, like=mask), empty(B, Ho, Wo, like=mask)
+    L.check(_lib().tg_mask_update(_p(mask), B, H, W, k, stride, pad, Ho, Wo, _p(mo), _p(ratio), _stream()), "tg_mask_update")
+    return mo, ratio
+
+
+def mask_up_merge(up_mask, skip_mask):
+    _chk(up_mask, "up_mask"); _chk(skip_mask, "skip_mask")
+    B, h, w = up_mask.shape
+    _, H, W = skip_mask.shape
+    out = torch.empty_like(skip_mask)
+    L.check(_lib().tg_mask_up_merge(_p(up_mask), _p(skip_mask), B, h, w, H, W, _p(out), _stream()), "tg_mask_up_merge")
+    return out
+
+
+def bn_stats(y, running_mean=None, running_var=None, nbt=None, eps=BN_EPS, momentum=BN_MOMENTUM):
+    _chk(y, "y")
+    Cc = y.shape[-1]
+    rows = y.numel() // Cc
+    mean, rstd = empty(Cc, like=y), empty(Cc, like=y)
+    lib = _lib()
+    ws = workspace(lib.tg_bn_ws_bytes(rows, Cc))
+    nbt_p = None if nbt is None else C.c_void_p(nbt.data_ptr())
+    L.check(lib.tg_bn_stats(_p(y), rows, Cc, eps, momentum, _p(mean), _p(rstd), _p(running_mean), _p(running_var), nbt_p,
+                            _p(ws), ws.numel() * 4, _stream()), "tg_bn_stats")
+    return mean, rstd
+
+
+def bn_eval_stats(running_mean, running_var, eps=BN_EPS):
+    Cc = running_mean.numel()
+    mean, rstd = torch.empty_like(running_mean), torch.empty_like(running_mean)
+    L.check(_lib().tg_bn_eval_stats(_p(running_mean), _p(running_var), Cc, eps, _p(mean), _p(rstd), _stream()), "tg_bn_eval_stats")
+    return mean, rstd
+
+
+def bn_running_update(mean, rstd, rows, running_mean, running_var, nbt, eps=BN_EPS, momentum=BN_MOMENTUM):
+    nbt_p = None if nbt is None else C.c_void_p(nbt.data_ptr())
+    L.check(_lib().tg_bn_running_update(_p(mean), _p(rstd), rows, mean.numel(), eps, momentum, _p(running_mean),
+                                        _p(running_var), nbt_p, _stream()), "tg_bn_running_update")
+
+
+def bn_act_fwd(y, mean, rstd, gamma, beta, act, slope=0.0):
+    _chk(y, "y")
+    Cc = y.shape[-1]
+    out = torch.empty_like(y)
+    L.check(_lib().tg_bn_act_fwd(_p(y), y.numel() // Cc, Cc, _p(mean), _p(rstd), _p(gamma.detach()), _p(beta.detach()), act,
+                                 slope, _p(out), _stream()), "tg_bn_act_fwd")
+    return out
+
+
+def bn_act_bwd(dout, y, mean, rstd, gamma, beta, act, slope=0.0, ratio=None, inplace=True):
+    """Returns (dy, dgamma, dbeta); dy overwrites dout when inplace."""
+    _chk(dout, "dout"); _chk(y, "y"); _chk(ratio, "ratio")
+    Cc = y.shape[-1]
+    rows = y.numel() // Cc
+    dy = dout if inplace else torch.empty_like(dout)
+    dgamma, dbeta = empty(Cc, like=y), empty(Cc, like=y)
+    lib = _lib()
+    ws = workspace(lib.tg_bn_ws_bytes(rows, Cc))
+    L.check(lib.tg_bn_act_bwd(_p(dout), _p(y), rows, Cc, _p(mean), _p(rstd), _p(gamma.detach()), _p(beta.detach()), act, slope,
+                              _p(ratio), _p(dy), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _stream()), "tg_bn_act_bwd")
+    return dy, dgamma, dbeta
+
+
+def act_bwd(dout, out, act, slope=0.0, ratio=None, inplace=True):
+    _chk(dout, "dout"); _chk(out, "out"); _chk(ratio, "ratio")
+    Cc = dout.shape[-1]
+    din = dout if inplace else torch.empty_like(dout)
+    L.check(_lib().tg_act_bwd(_p(dout), _p(out), dout.numel() // Cc, Cc, act, slope, _p(ratio), _p(din), _stream()), "tg_act_bwd")
+    return din
+
+
+def upcat_fwd(up, skip, H, W):
+    _chk(up, "up"); _chk(skip, "skip")
+    B, h, w, Cu = up.shape
+    Cs = 0 if skip is None else skip.shape[3]
+    out = empty(B, H, W, Cu + Cs, like=up)
+    L.check(_lib().tg_upcat_fwd(_p(up), _p(skip), B, h, w, Cu, H, W, Cs, _p(out), _stream()), "tg_upcat_fwd")
+    return out
+
+
+def upcat_bwd(dout, h, w, Cu, want_skip=True):
+    _chk(dout, "dout")
+    B, H, W, Ct = dout.shape
+    Cs = Ct - Cu
+    dup = empty(B, h, w, Cu, like=dout)
+    dskip = empty(B, H, W, Cs, like=dout) if (Cs > 0 and want_skip) else None
+    L.check(_lib().tg_upcat_bwd(_p(dout), B, h, w, Cu, H, W, Cs, _p(dup), _p(dskip), _stream()), "tg_upcat_bwd")
+    return dup, dskip
+
+
+def sigmoid_composite_fwd(logits, x, mask):
+    out = torch.empty_like(x)
+    L.check(_lib().tg_sigmoid_composite_fwd(_p(logits), _p(x), _p(mask), x.numel(), _p(out), _stream()), "tg_sigmoid_composite_fwd")
+    return out
+
+
+def sigmoid_composite_bwd(dout, logits, mask, want_dx=False):
+    _chk(dout, "dout")
+    dz = torch.empty_like(logits)
+    dx = torch.empty_like(dout) if want_dx else None
+    L.check(_lib().tg_sigmoid_composite_bwd(_p(dout), _p(logits), _p(mask), dout.numel(), _p(dz), _p(dx), _stream()),
+            "tg_sigmoid_composite_bwd")
+    return dz, dx
+
+
+def maxpool2_fwd(x):
+    B, H, W, Cc = x.shape
+    out = empty(B, H // 2, W // 2, Cc, like=x)
+    L.check(_lib().tg_maxpool2_fwd(_p(x), B, H, W, Cc, _p(out), _stream()), "tg_maxpool2_fwd")
+    return out
+
+
+def maxpool2_bwd(dout, x):
+    B, H, W, Cc = x.shape
+    dx = torch.empty_like(x)
+    L.check(_lib().tg_maxpool2_bwd(_p(dout), _p(x), B, H, W, Cc, _p(dx), _stream()), "tg_maxpool2_bwd")
+    return dx
+
+
+def pixel_losses(pred, target, mask, w_l1, w_tv, w_bnd, l1_weight=None, gscale=None, dpred=None, accumulate=False,
+                 want_grad=True, eps=1e-6):
+    """-> (out5 device tensor {l1, tv, boundary, sum(band), total}, dpred or None)."""
+    _chk(pred, "pred"); _chk(target, "target"); _chk(mask, "mask"); _chk(l1_weight, "l1_weight")
+    B, H, W = pred.shape
+    out5 = empty(5, like=pred)
+    if want_grad and dpred is None:
+        dpred = torch.empty_like(pred)
+        accumulate = False
+    lib = _lib()
+    ws = workspace(lib.tg_pixel_loss_ws_bytes(B, H, W))
+    L.check(lib.tg_pixel_losses(_p(pred), _p(target), _p(mask), _p(l1_weight), B, H, W, w_l1, w_tv, w_bnd, eps, _p(gscale),
+                                _p(out5), _p(dpred) if want_grad else None, 1 if accumulate else 0, _p(ws), ws.numel() * 4,
+                                _stream()), "tg_pixel_losses")
+    return out5, (dpred if want_grad else None)
+
+
+def l1_mean(a, b, coef=1.0, gscale=None, want_grad=True):
+    _chk(a, "a"); _chk(b, "b")
+    out = empty(1, like=a)
+    da = torch.empty_like(a) if want_grad else None
+    lib = _lib()
+    ws = workspace(lib.tg_reduce_ws_bytes(a.numel()))
+    L.check(lib.tg_l1_mean(_p(a), _p(b), a.numel(), coef, _p(gscale), _p(out), _p(da), _p(ws), ws.numel() * 4, _stream()),
+            "tg_l1_mean")
+    return out, da
+
+
+def bce_logits(z, target, coef=1.0, gscale=None, want_grad=True):
+    _chk(z, "z")
+    out = empty(1, like=z)
+    dz = torch.empty_like(z) if want_grad else None
+    lib = _lib()
+    ws = workspace(lib.tg_reduce_ws_bytes(z.numel()))
+    L.check(lib.tg_bce_logits(_p(z), z.numel(), target, coef, _p(gscale), _p(out), _p(dz), _p(ws), ws.numel() * 4, _stream()),
+            "tg_bce_logits")
+    return out, dz
+
+
+def _dense_layouts(t):
+    """Which dense physical orders a tensor's strides describe: 'c' (row-major) and/or 'cl'."""
+    out = set()
+    if t.is_contiguous():
+        out.add("c")
+    if t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous():
+        out.add("cl")
+    return out
+
+
+def adam_(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    """In-place Adam on the physical storage of p/g/m/v (which must share one dense layout)."""
+    lay = _dense_layouts(p)
+    for t, nm in ((g, "g"), (m, "m"), (v, "v")):
+        if t.shape != p.shape or not (_dense_layouts(t) & lay):
+            raise L.TgError(f"adam_: {nm} layout {tuple(t.shape)}/{t.stride()} differs from the parameter's "
+                            f"{tuple(p.shape)}/{p.stride()}")
+    L.check(_lib().tg_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _stream()), "tg_adam")
+
+
+def axpby_(x, a, b, y):
+    """y = a*x + b*y (same dense layout)."""
+    assert x.shape == y.shape and (_dense_layouts(x) & _dense_layouts(y)), (x.shape, x.stride(), y.stride())
+    L.check(_lib().tg_axpby(_p(x), a, b, _p(y), y.numel(), _stream()), "tg_axpby")
+    return y
+
+
+def lincomb(x, a, y, b):
+    out = torch.empty_like(x)
+    L.check(_lib().tg_lincomb(_p(x), a, _p(y), b, _p(out), x.numel(), _stream()), "tg_lincomb")
+    return out
+
+
+def mul(a, b):
+    _chk(a, "a"); _chk(b, "b")
+    out = torch.empty_like(a)
+    L.check(_lib().tg_mul(_p(a), _p(b), _p(out), a.numel(), _stream()), "tg_mul")
+    return out
+
+
+def nchw_to_nhwc(x):
+    """Logical [B,C,H,W] contiguous tensor -> [B,H,W,C] contiguous (C==1 is a free reshape)."""
+    B, Cc, H, W = x.shape
+    x = x if x.is_contiguous() else x.contiguous()
+    if Cc == 1:
+        return x.reshape(B, H, W, 1)
+    y = empty(B, H, W, Cc, like=x)
+    L.check(_lib().tg_nchw_to_nhwc(_p(x), B, Cc, H, W, _p(y), _stream()), "tg_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x):
+    B, H, W, Cc = x.shape
+    if Cc == 1:
+        return x.reshape(B, 1, H, W)
+    y = empty(B, Cc, H, W, like=x)
+    L.check(_lib().tg_nhwc_to_nchw(_p(x), B, Cc, H, W, _p(y), _stream()), "tg_nhwc_to_nchw")
+    return y

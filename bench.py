@@ -45,7 +45,8 @@ def prof_summary(lib, kind):
 def cpu_baseline(seconds_budget=25.0):
     """CPU oracle train step on the host cores: bounded sample of the same workload (batch 4, 256x256)."""
     from oracle import terragan_oracle as Orc
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives a 1-GPU job a 16-core CPU share although os.cpu_count() reports the whole host
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
     st = Orc.TrainState(0)
     b = 4
     real, mask = Orc.synth_batch(b, TILE, 1000)
@@ -70,6 +71,7 @@ def main():
     ap.add_argument("--size", type=int, default=TILE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--prof-dump", default=None, help="write the per-launch table of the instrumented pass to this CSV")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,6 +139,8 @@ def main():
         run(2)
         torch.cuda.synchronize()
         lib.tg_prof_enable(0)
+        if args.prof_dump:
+            lib.tg_prof_dump(args.prof_dump.encode())
         ms0, n0, fl0, by0 = prof_summary(lib, 0)
         ms1, n1, fl1, by1 = prof_summary(lib, 1)
         ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0

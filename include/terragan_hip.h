@@ -194,6 +194,8 @@ int tg_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, tg_str
  * region), returns the totals for `kind` and consumes its records. */
 int tg_prof_enable(int on);
 int tg_prof_summary(int kind, double* total_ms, int64_t* launches, double* flops, double* bytes);
+/* One CSV row per recorded launch (kind,cfg,M,N,K,C,splits,ms,gflop,alg_mb); records are kept. */
+int tg_prof_dump(const char* path);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@ struct ProfRec {
     hipEvent_t a, b;
     int kind;  // 0 = igemm (fwd/dgrad), 1 = wgrad
     double flops, bytes;
+    int M, N, K, C, splits, cfg;
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -33,10 +34,13 @@ struct ProfScope {
     bool on = false;
     ProfRec r{};
     hipStream_t s;
-    ProfScope(hipStream_t st, int kind, double flops, double bytes) : s(st) {
+    ProfScope(hipStream_t st, int kind, double flops, double bytes, int M = 0, int N = 0, int K = 0, int C = 0, int splits = 1,
+              int cfg = 0)
+        : s(st) {
         if (!g_prof_on) return;
         on = true;
         r.kind = kind; r.flops = flops; r.bytes = bytes;
+        r.M = M; r.N = N; r.K = K; r.C = C; r.splits = splits; r.cfg = cfg;
         (void)hipEventCreate(&r.a);
         (void)hipEventCreate(&r.b);
         (void)hipEventRecord(r.a, s);
@@ -52,6 +56,22 @@ struct ProfScope {
 extern "C" int tg_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
+    return TG_OK;
+}
+// Writes one CSV row per recorded launch (kind,cfg,M,N,K,C,splits,ms,gflop,alg_mb) without consuming the records.
+extern "C" int tg_prof_dump(const char* path) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    FILE* f = fopen(path, "w");
+    if (!f) { tg_set_error("tg_prof_dump: cannot open %s", path); return TG_ERR_ARG; }
+    fprintf(f, "kind,cfg,M,N,K,C,splits,ms,gflop,alg_mb\n");
+    for (auto& r : g_prof) {
+        (void)hipEventSynchronize(r.b);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.a, r.b);
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.5f,%.4f,%.3f\n", r.kind, r.cfg, r.M, r.N, r.K, r.C, r.splits, t, r.flops / 1e9,
+                r.bytes / 1e6);
+    }
+    fclose(f);
     return TG_OK;
 }
 // Synchronises the recorded events (host-blocking; never called inside a timed region) and returns the
@@ -341,7 +361,7 @@ static int launch_igemm_cfg(const IGemmParams& p, hipStream_t s) {
         // algorithmic bytes: source pixels touched once + row scale/mask + weights + output
         const double by = 4.0 * ((double)p.B * p.IH * p.IW * p.C + (double)p.M + (double)p.N * p.Ktot + (double)p.M * p.N +
                                  (p.amask ? (double)p.B * p.IH * p.IW : 0.0));
-        ProfScope ps(s, 0, 2.0 * p.M * (double)p.N * p.Ktot, by);
+        ProfScope ps(s, 0, 2.0 * p.M * (double)p.N * p.Ktot, by, p.M, p.N, p.Ktot, p.C, p.splits, BN + (SCALAR ? 1 : 0));
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     }
     TG_CHECK_LAUNCH("igemm_kernel");
@@ -718,7 +738,7 @@ static int launch_wgrad_cfg(const WgradParams& p, hipStream_t s) {
     {
         const double by = 4.0 * ((double)p.B * p.H * p.W * p.C + (double)p.Mpix * p.Cout + (double)p.Cout * p.Ktot +
                                  (double)p.Mpix + (p.amask ? (double)p.B * p.H * p.W : 0.0));
-        ProfScope ps(s, 1, 2.0 * p.Mpix * (double)p.Cout * p.Ktot, by);
+        ProfScope ps(s, 1, 2.0 * p.Mpix * (double)p.Cout * p.Ktot, by, p.Cout, p.Ktot, p.Mpix, p.C, p.splits, BM);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     }
     TG_CHECK_LAUNCH("wgrad_kernel");

@@ -86,6 +86,39 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, int64_t rows, int C
     }
 }
 
+
+// Second stage shared by every column reduction: 16 columns x 16 partial-row lanes per 256-thread block;
+// lane rl sums partial rows rl, rl+16, ... in fp64 (fixed order), the 16 lanes are combined through LDS in
+// a fixed order as well -> deterministic.  Returns true in the thread that owns column *c_out (rl == 0).
+constexpr int FR_COLS = 16, FR_LANES = 16;
+template <int NQ>
+__device__ __forceinline__ bool final_reduce(const float* __restrict__ partial, int nblocks, int C, double (&out)[NQ],
+                                             int* c_out) {
+    __shared__ double fr[NQ][FR_LANES][FR_COLS];
+    const int col = threadIdx.x % FR_COLS, rl = threadIdx.x / FR_COLS;
+    const int c = blockIdx.x * FR_COLS + col;
+    double acc[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) acc[i] = 0.0;
+    if (c < C)
+        for (int b = rl; b < nblocks; b += FR_LANES)
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) acc[i] += (double)partial[((size_t)b * NQ + i) * C + c];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) fr[i][rl][col] = acc[i];
+    __syncthreads();
+    *c_out = c;
+    if (rl != 0 || c >= C) return false;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        double s = 0.0;
+        for (int l = 0; l < FR_LANES; ++l) s += fr[i][l][col];
+        out[i] = s;
+    }
+    return true;
+}
+static inline int fr_grid(int C) { return cdiv(C, FR_COLS); }
+
 // ---- plain column sum (conv bias gradient) --------------------------------------------------------
 struct ColSumF {
     const float* x;
@@ -94,11 +127,9 @@ struct ColSumF {
 };
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int C,
                                                            float* __restrict__ out) {
-    int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * C + c];
-    out[c] = (float)s;
+    double s[1];
+    int c;
+    if (final_reduce<1>(partial, nblocks, C, s, &c)) out[c] = (float)s[0];
 }
 size_t tg_colsum_ws_floats(int64_t rows, int C) {
     ColGeom g = col_geom(rows, C);
@@ -111,7 +142,7 @@ int tg_colsum_launch(const float* x, int64_t rows, int C, float* out, float* ws,
     hipLaunchKernelGGL((colreduce_kernel<1, ColSumF>), dim3(g.grid), dim3(256), 0, s, f, rows, C, g.cpp, g.rlanes,
                        g.rows_per_block, ws);
     TG_CHECK_LAUNCH("colsum");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, g.grid, C, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(fr_grid(C)), dim3(256), 0, s, ws, g.grid, C, out);
     TG_CHECK_LAUNCH("colsum_final");
     return TG_OK;
 }
@@ -199,17 +230,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float momentum, float* __restrict__ mean_out,
                                                           float* __restrict__ rstd_out, float* __restrict__ rm,
                                                           float* __restrict__ rv, int64_t* __restrict__ nbt) {
-    int c = blockIdx.x * 256 + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;
-    if (c >= C) return;
-    double s = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-        s += (double)partial[((size_t)b * 2 + 0) * C + c];
-        s2 += (double)partial[((size_t)b * 2 + 1) * C + c];
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    double q[2];
+    int c;
+    if (!final_reduce<2>(partial, nblocks, C, q, &c)) return;
     const double n = (double)rows;
-    const double md = s / n;
-    double var = s2 / n - md * md;
+    const double md = q[0] / n;
+    double var = q[1] / n - md * md;
     if (var < 0.0) var = 0.0;
     const double mean = (double)y[c] + md;
     mean_out[c] = (float)mean;
@@ -234,7 +261,7 @@ extern "C" int tg_bn_stats(const float* y, int64_t rows, int C, float eps, float
     hipLaunchKernelGGL((colreduce_kernel<2, BnStatF>), dim3(g.grid), dim3(256), 0, S(stream), f, rows, C, g.cpp, g.rlanes,
                        g.rows_per_block, ws);
     TG_CHECK_LAUNCH("bn_stats");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), ws, g.grid, C, y, rows, eps,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(fr_grid(C)), dim3(256), 0, S(stream), ws, g.grid, C, y, rows, eps,
                        momentum, save_mean, save_rstd, running_mean, running_var, num_batches_tracked);
     TG_CHECK_LAUNCH("bn_finalize");
     return TG_OK;
@@ -321,15 +348,11 @@ struct BnBwdF {
 };
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ partial, int nblocks, int C,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-        s += (double)partial[((size_t)b * 2 + 0) * C + c];
-        s2 += (double)partial[((size_t)b * 2 + 1) * C + c];
-    }
-    dbeta[c] = (float)s;
-    dgamma[c] = (float)s2;
+    double q[2];
+    int c;
+    if (!final_reduce<2>(partial, nblocks, C, q, &c)) return;
+    dbeta[c] = (float)q[0];
+    dgamma[c] = (float)q[1];
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                            int64_t rows, int C, const float* __restrict__ mean,
@@ -360,7 +383,7 @@ extern "C" int tg_bn_act_bwd(const float* dout, const float* y, int64_t rows, in
     hipLaunchKernelGGL((colreduce_kernel<2, BnBwdF>), dim3(g.grid), dim3(256), 0, S(stream), f, rows, C, g.cpp, g.rlanes,
                        g.rows_per_block, ws);
     TG_CHECK_LAUNCH("bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), ws, g.grid, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fr_grid(C)), dim3(256), 0, S(stream), ws, g.grid, C, dgamma, dbeta);
     TG_CHECK_LAUNCH("bn_bwd_final");
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * C, 256)), dim3(256), 0, S(stream), dout, y, rows, C, mean,
                        rstd, gamma, beta, act, slope, ratio, dgamma, dbeta, dy);

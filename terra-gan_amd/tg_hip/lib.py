@@ -2,6 +2,11 @@
 import ctypes as C
 import os
 
+# torch MUST be imported before the library is dlopen'ed: the torch wheel bundles its own ROCm runtime
+# (libamdhip64.so.7, libhsa-runtime64) and libterragan_hip.so has to bind to THAT copy -- the same
+# SONAME under /opt/rocm is a different build, and two HIP runtimes in one process cannot share streams.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libterragan_hip.so")
 
@@ -54,6 +59,7 @@ SIGNATURES = {
     "tg_bn_running_update": (I, [P, P, I64, I, F, F, P, P, P, P]),
     "tg_prof_enable": (I, [I]),
     "tg_prof_summary": (I, [I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "tg_prof_dump": (I, [C.c_char_p]),
     "tg_nchw_to_nhwc": (I, [P, I, I, I, I, P, P]),
     "tg_nhwc_to_nchw": (I, [P, I, I, I, I, P, P]),
 }

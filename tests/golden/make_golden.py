@@ -294,7 +294,7 @@ def _build(ref_gen, ref_disc, ref_losses, seed=0):
 def gen_steps(ref_gen, ref_disc, ref_losses):
     out = {}
     bce = nn.BCEWithLogitsLoss()
-    for tag, b, size, nsteps, seed0 in [("c1_256", 1, 256, 3, 1), ("b2_64", 2, 64, 3, 40)]:
+    for tag, b, size, nsteps, seed0 in [("c1_256", 1, 256, 3, 1), ("b4_128", 4, 128, 3, 40)]:
         G, D, crit, oG, oD = _build(ref_gen, ref_disc, ref_losses)
         G.train(), D.train()
         out[f"{tag}/cfg"] = np.array([b, size, nsteps, seed0], dtype=np.int64)
@@ -319,7 +319,7 @@ def gen_steps(ref_gen, ref_disc, ref_losses):
                         put(out, f"{tag}/s{s}/buf/{n}", buf, full_limit=1024)
     # data-parallel emulation: N micro-batches, identical weights, mean grads, one Adam
     import copy
-    for tag, n, b, size in [("dp2_64", 2, 2, 64)]:
+    for tag, n, b, size in [("dp2_128", 2, 4, 128)]:
         G, D, crit, oG, oD = _build(ref_gen, ref_disc, ref_losses)
         out[f"{tag}/cfg"] = np.array([n, b, size], dtype=np.int64)
         gens, gsum = [], {}

@@ -151,7 +151,7 @@ def _check_weights(gold, prefix, st, lr_steps):
             assert abs(float(prm[k].double().abs().sum()) - ref[1]) <= tol, (prefix, pre, k)
 
 
-@pytest.mark.parametrize("tag", ["b2_64", "c1_256"])
+@pytest.mark.parametrize("tag", ["b4_128", "c1_256"])
 def test_train_steps(tag):
     gold = GU.load("steps")
     b, size, nsteps, seed0 = [int(v) for v in gold[f"{tag}/cfg"]]
@@ -176,12 +176,12 @@ def test_train_steps(tag):
 
 def test_dp_emulation():
     gold = GU.load("steps")
-    n, b, size = [int(v) for v in gold["dp2_64/cfg"]]
+    n, b, size = [int(v) for v in gold["dp2_128/cfg"]]
     st = O.TrainState(0)
     batches = [O.synth_batch(b, size, 1000 + r) for r in range(n)]
     gens, scal = O.dp_train_step(st, [x for x, _ in batches], [m for _, m in batches])
     for r in range(n):
         for k in ["g_total", "d_loss"]:
-            ref = float(gold[f"dp2_64/r{r}/{k}"])
+            ref = float(gold[f"dp2_128/r{r}/{k}"])
             assert abs(float(scal[r][k]) - ref) <= 2e-6 * abs(ref) + 1e-7, (r, k)
-    _check_weights(gold, "dp2_64", st, 2e-4)
+    _check_weights(gold, "dp2_128", st, 2e-4)

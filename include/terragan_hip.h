@@ -110,10 +110,12 @@ int tg_act_bwd(const float* dout, const float* out, int64_t rows, int C, int act
 
 /* ---- decoder plumbing: bilinear x2 upsample (+) channel concat ------------------------------- */
 
-/* out[B][H][W][Cu+Cs] = cat( pad(bilinear_up2(up[B][h][w][Cu])), skip[B][H][W][Cs] )
- * (generator.py:50,52,67,70,73; align_corners=False; skip may be NULL with Cs=0). */
-int tg_upcat_fwd(const float* up, const float* skip, int B, int h, int w, int Cu, int H, int W,
-                 int Cs, float* out, tg_stream_t stream);
+/* out[B][H][W][Cu+Cs] = cat( pad(bilinear_up2(up[B][h][w][Cu])), skip[B][H][W][Cs] ) (.) out_mask
+ * (generator.py:50,52,67,70,73; align_corners=False; skip may be NULL with Cs=0).  out_mask
+ * [B][H][W] (NULL = 1) is the merged decoder mask: writing the concat already multiplied by it is the
+ * `input * mask` of the consuming PConv2d (pconv.py:27), so that conv and its wgrad read it unmasked. */
+int tg_upcat_fwd(const float* up, const float* skip, const float* out_mask, int B, int h, int w,
+                 int Cu, int H, int W, int Cs, float* out, tg_stream_t stream);
 /* adjoint: dup[B][h][w][Cu] = bilinear_up2^T(dout[..., :Cu]);  dskip = dout[..., Cu:]. */
 int tg_upcat_bwd(const float* dout, int B, int h, int w, int Cu, int H, int W, int Cs, float* dup,
                  float* dskip, tg_stream_t stream);

@@ -10,6 +10,8 @@
 // row pitch so that the ds_read_b128 operand fetch (4 consecutive k per lane) is bank-conflict free;
 // MFMA number e of a k-group consumes element e of that fetch on both operands, i.e. k = 8g+4h+e
 // for lane half h -- a permutation of the k order, which a sum over k does not care about.
+#include <stdlib.h>
+
 #include <mutex>
 #include <vector>
 
@@ -122,6 +124,16 @@ struct IGemmParams {
     int accumulate;
 };
 
+// XCD-aware work remap (bijective): hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
+// ids b and b+8 share an L2.  Map id -> work index such that each XCD gets a CONTIGUOUS range of work items;
+// callers order work items so that neighbours share operands (same pixels, different channel tiles).
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+__device__ __forceinline__ int xcd_remap(int id, int total) {
+    const int xcd = id & 7, slot = id >> 3;
+    const int qd = total >> 3, rm = total & 7;
+    return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
+}
+
 __device__ __forceinline__ size_t dst_pixel(const IGemmParams& p, int m) {
     if (p.ds == 1 && p.OH == p.DH && p.OW == p.DW) return (size_t)m;
     int ox = m % p.OW;
@@ -165,74 +177,102 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
 
     f32x4 ra[A_LOADS], rw[B_LOADS];
 
-    auto gload = [&](int t) {
-        if constexpr (!SCALAR) {
-            const int tap = t / p.nchunks;
-            const int c0 = (t - tap * p.nchunks) * 32 + 4 * kc;
-            const int ty = tap / p.TW, tx = tap - ty * p.TW;
-            const int dyy = ty * p.tstep, dxx = tx * p.tstep;
-            const int widx = ((p.ky0 + ty * p.kstep) * p.KW + (p.kx0 + tx * p.kstep)) * p.C + c0;
-            const bool cv = c0 < p.C;
+    // loader state for the NEXT K step (vector path): tap (l_ty, l_tx) and channel chunk l_ch, advanced
+    // incrementally -- no integer division in the loop
+    int l_ty = 0, l_tx = 0, l_ch = 0;
+    if constexpr (!SCALAR) {
+        const int tap0 = t_begin / p.nchunks;
+        l_ch = t_begin - tap0 * p.nchunks;
+        l_ty = tap0 / p.TW;
+        l_tx = tap0 - l_ty * p.TW;
+    }
+    int g_c0 = 0, g_dyy = 0, g_dxx = 0, g_widx = 0;
+    bool g_cv = false;
+    // latch the addressing of the step being loaded, then advance the state
+    auto gbegin = [&]() {
+        g_c0 = l_ch * 32 + 4 * kc;
+        g_dyy = l_ty * p.tstep;
+        g_dxx = l_tx * p.tstep;
+        g_widx = ((p.ky0 + l_ty * p.kstep) * p.KW + (p.kx0 + l_tx * p.kstep)) * p.C + g_c0;
+        g_cv = g_c0 < p.C;
+        if (++l_ch == p.nchunks) {
+            l_ch = 0;
+            if (++l_tx == p.TW) { l_tx = 0; ++l_ty; }
+        }
+    };
+    // quarter `part` (0..3) of the step's global loads: A rows i = part (mod 4), B rows j = part (mod 4)
+    auto gpart = [&](int part) {
 #pragma unroll
-            for (int i = 0; i < A_LOADS; ++i) {
-                int iy = ry[i] + dyy, ix = rx[i] + dxx;
-                bool ok = rv[i] && cv && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) {
-                    size_t pix = ((size_t)rb[i] * p.IH + iy) * p.IW + ix;
-                    v = *reinterpret_cast<const f32x4*>(p.src + pix * p.C + c0);
-                    if (p.amask) v *= p.amask[pix];
-                }
-                ra[i] = v;
+        for (int i = 0; i < A_LOADS; ++i) {
+            if ((i & 3) != part) continue;
+            int iy = ry[i] + g_dyy, ix = rx[i] + g_dxx;
+            bool ok = rv[i] && g_cv && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                size_t pix = ((size_t)rb[i] * p.IH + iy) * p.IW + ix;
+                v = *reinterpret_cast<const f32x4*>(p.src + pix * p.C + g_c0);
+                if (p.amask) v *= p.amask[pix];
             }
+            ra[i] = v;
+        }
 #pragma unroll
-            for (int j = 0; j < B_LOADS; ++j) {
-                int n = n0 + r0 + 32 * j;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (n < p.N && cv) v = *reinterpret_cast<const f32x4*>(p.wmat + (size_t)n * p.Kfull + widx);
-                rw[j] = v;
-            }
-        } else {
-            // any C (1, 3, ...): K index decoded per element
-            int tapv[4], cval[4], dyv[4], dxv[4], wv[4];
-            bool kv[4];
+        for (int j = 0; j < B_LOADS; ++j) {
+            if ((j & 3) != part) continue;
+            int n = n0 + r0 + 32 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.N && g_cv) v = *reinterpret_cast<const f32x4*>(p.wmat + (size_t)n * p.Kfull + g_widx);
+            rw[j] = v;
+        }
+    };
+    auto gload_scalar = [&](int t) {
+        // any C (1, 3, ...): K index decoded per element
+        int tapv[4], cval[4], dyv[4], dxv[4], wv[4];
+        bool kv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int k = t * 32 + 4 * kc + e;
+            kv[e] = k < p.Ktot;
+            int kk = kv[e] ? k : 0;
+            tapv[e] = kk / p.C;
+            cval[e] = kk - tapv[e] * p.C;
+            int ty = tapv[e] / p.TW, tx = tapv[e] - ty * p.TW;
+            dyv[e] = ty * p.tstep;
+            dxv[e] = tx * p.tstep;
+            wv[e] = ((p.ky0 + ty * p.kstep) * p.KW + (p.kx0 + tx * p.kstep)) * p.C + cval[e];
+        }
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int k = t * 32 + 4 * kc + e;
-                kv[e] = k < p.Ktot;
-                int kk = kv[e] ? k : 0;
-                tapv[e] = kk / p.C;
-                cval[e] = kk - tapv[e] * p.C;
-                int ty = tapv[e] / p.TW, tx = tapv[e] - ty * p.TW;
-                dyv[e] = ty * p.tstep;
-                dxv[e] = tx * p.tstep;
-                wv[e] = ((p.ky0 + ty * p.kstep) * p.KW + (p.kx0 + tx * p.kstep)) * p.C + cval[e];
-            }
-#pragma unroll
-            for (int i = 0; i < A_LOADS; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int iy = ry[i] + dyv[e], ix = rx[i] + dxv[e];
-                    bool ok = rv[i] && kv[e] && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-                    if (ok) {
-                        size_t pix = ((size_t)rb[i] * p.IH + iy) * p.IW + ix;
-                        float s = p.src[pix * p.C + cval[e]];
-                        if (p.amask) s *= p.amask[pix];
-                        v[e] = s;
-                    }
+                int iy = ry[i] + dyv[e], ix = rx[i] + dxv[e];
+                bool ok = rv[i] && kv[e] && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+                if (ok) {
+                    size_t pix = ((size_t)rb[i] * p.IH + iy) * p.IW + ix;
+                    float sv = p.src[pix * p.C + cval[e]];
+                    if (p.amask) sv *= p.amask[pix];
+                    v[e] = sv;
                 }
-                ra[i] = v;
             }
+            ra[i] = v;
+        }
 #pragma unroll
-            for (int j = 0; j < B_LOADS; ++j) {
-                int n = n0 + r0 + 32 * j;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < B_LOADS; ++j) {
+            int n = n0 + r0 + 32 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n < p.N && kv[e]) v[e] = p.wmat[(size_t)n * p.Kfull + wv[e]];
-                rw[j] = v;
-            }
+            for (int e = 0; e < 4; ++e)
+                if (n < p.N && kv[e]) v[e] = p.wmat[(size_t)n * p.Kfull + wv[e]];
+            rw[j] = v;
+        }
+    };
+    auto gload = [&](int t) {
+        if constexpr (!SCALAR) {
+            gbegin();
+#pragma unroll
+            for (int part = 0; part < 4; ++part) gpart(part);
+        } else {
+            gload_scalar(t);
         }
     };
     auto sstore = [&](int buf) {
@@ -265,11 +305,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
         for (int t = t_begin; t < t_end; ++t) {
             const int cur = (t - t_begin) & 1;
             const bool more = (t + 1) < t_end;
-            if (more) gload(t + 1);
+            if constexpr (SCALAR) {
+                if (more) gload_scalar(t + 1);
+            } else {
+                if (more) gbegin();
+            }
             const float* Ab = As + cur * BM * LDK;
             const float* Bb = Bs + cur * BN * LDK;
 #pragma unroll
             for (int kg = 0; kg < 4; ++kg) {
+                // a quarter of the next step's global loads rides behind each MFMA group
+                if constexpr (!SCALAR) {
+                    if (more) gpart(kg);
+                }
                 f32x4 a[WM], b[WN];
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
@@ -372,6 +420,293 @@ static int launch_igemm_cfg(const IGemmParams& p, hipStream_t s) {
     return TG_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v2: patch-staged implicit GEMM for stride-1 gathers (every stride-1 forward conv and EVERY dgrad,
+// whose parity classes are stride-1 over the dy grid).  The workgroup owns a TH x TW block of output
+// pixels of one image; for each 32-channel chunk the (TH+taps-1) x (TW+taps-1) input patch is staged
+// into LDS ONCE (mask multiply and bounds handling happen there, once per pixel) and all taps read their
+// A fragments straight from it at a shifted base -- 9x fewer A-side global loads and index math for a
+// 3x3 conv than gathering per tap.  Only the weight tile streams per (chunk, tap), double-buffered.
+// ------------------------------------------------------------------------------------------------
+struct PatchGeom {
+    int tiles_x, tiles_y;   // output tiles per image
+    int PH, PW;             // patch size in source pixels
+    int sy_min, sx_min;     // min over taps of (sy0 + ty*tstep), (sx0 + tx*tstep)
+    int chunks_per_split;
+};
+
+template <int TH_, int TW_, int WAVES_M, int WAVES_N, int WM, int WN, int MAXPL>
+__global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, const PatchGeom q) {
+    constexpr int BM = TH_ * TW_, BN = WAVES_N * WN * 32, LDK = 36;
+    constexpr int B_LOADS = BN / 32;
+    static_assert(BM == WAVES_M * WM * 32 && WAVES_M * WAVES_N == 4, "tile/wave mismatch");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Bs = smem;                    // [2][BN][LDK]
+    float* Ps = smem + 2 * BN * LDK;     // [PH*PW][LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int kc = tid & 7, r0 = tid >> 3;
+    // flat (patch tile, N tile) index, XCD-remapped so the N tiles of one patch share an L2
+    const int nty = cdiv_dev(p.N, BN);
+    const int work = xcd_remap(blockIdx.x, q.tiles_x * q.tiles_y * p.B * nty);
+    const int n0 = (work % nty) * BN;
+    int tile = work / nty;
+    const int txi = tile % q.tiles_x;
+    tile /= q.tiles_x;
+    const int tyi = tile % q.tiles_y;
+    const int b = tile / q.tiles_y;
+    const int oy0 = tyi * TH_, ox0 = txi * TW_;
+    const int py0 = oy0 * p.ss + q.sy_min, px0 = ox0 * p.ss + q.sx_min;
+    const int ppix = q.PH * q.PW;
+
+    // patch slots owned by this thread: fixed for the whole K loop
+    uint32_t poff[MAXPL];
+    float pmul[MAXPL];
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+        const int idx = tid + 256 * i;
+        const int pp = idx >> 3;
+        poff[i] = 0;
+        pmul[i] = 0.f;
+        if (pp < ppix) {
+            const int py = pp / q.PW, px = pp - py * q.PW;
+            const int iy = py0 + py, ix = px0 + px;
+            if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) {
+                const uint32_t pix = ((uint32_t)b * p.IH + iy) * p.IW + ix;
+                poff[i] = pix * (uint32_t)p.C + 4 * kc;
+                pmul[i] = p.amask ? p.amask[pix] : 1.f;
+            }
+        }
+    }
+    uint32_t boff[B_LOADS];
+    bool bok[B_LOADS];
+#pragma unroll
+    for (int j = 0; j < B_LOADS; ++j) {
+        const int n = n0 + r0 + 32 * j;
+        bok[j] = n < p.N;
+        boff[j] = (uint32_t)(bok[j] ? n : 0) * (uint32_t)p.Kfull + 4 * kc;
+    }
+    // A-fragment bases: row r of the M tile is output pixel (r / TW, r % TW)
+    int abase[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int r = (wm * WM + i) * 32 + (lane & 31);
+        abase[i] = ((r / TW_) * p.ss * q.PW + (r % TW_) * p.ss) * LDK + 4 * (lane >> 5);
+    }
+    const int brow = wn * WN * 32 + (lane & 31);
+    const int ko = 4 * (lane >> 5);
+    const int ntaps = p.TH * p.TW;
+    const int c_begin = blockIdx.z * q.chunks_per_split;
+    const int c_end = min(p.nchunks, c_begin + q.chunks_per_split);
+
+    // Patch staging registers.  Small patches (<= 8 slots/thread) are prefetched during the last tap of the
+    // previous chunk; the 16x16 tile (up to 12 slots) would push the kernel past 256 VGPRs, so it reloads its
+    // patch in two register batches behind the chunk-boundary barrier instead.
+    constexpr bool PREFETCH = MAXPL <= 8;
+    constexpr int PB = PREFETCH ? MAXPL : (MAXPL + 1) / 2;      // slots per register batch
+    f32x4 rp[PB], rw[B_LOADS];
+    auto pload = [&](int c, int batch) {
+        const bool cv = c * 32 + 4 * kc < p.C;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int sl = batch * PB + i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (sl < MAXPL && pmul[sl] != 0.f && cv) v = *reinterpret_cast<const f32x4*>(p.src + poff[sl] + c * 32) * pmul[sl];
+            rp[i] = v;
+        }
+    };
+    auto pstore = [&](int batch) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int sl = batch * PB + i;
+            const int idx = tid + 256 * sl;
+            if (sl < MAXPL && (idx >> 3) < ppix) *reinterpret_cast<f32x4*>(Ps + (idx >> 3) * LDK + 4 * kc) = rp[i];
+        }
+    };
+    constexpr int NBATCH = PREFETCH ? 1 : 2;
+    auto wload = [&](int c, int tap) {
+        const int ty = tap / p.TW, tx = tap - ty * p.TW;
+        const uint32_t widx = (uint32_t)(((p.ky0 + ty * p.kstep) * p.KW + (p.kx0 + tx * p.kstep)) * p.C + c * 32);
+        const bool cv = c * 32 + 4 * kc < p.C;
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (bok[j] && cv) v = *reinterpret_cast<const f32x4*>(p.wmat + boff[j] + widx);
+            rw[j] = v;
+        }
+    };
+    auto wstore = [&](int buf) {
+        float* Bb = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) *reinterpret_cast<f32x4*>(Bb + (r0 + 32 * j) * LDK + 4 * kc) = rw[j];
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end && ntaps > 0) {
+        wload(c_begin, 0);
+#pragma unroll
+        for (int bt = 0; bt < NBATCH; ++bt) {
+            pload(c_begin, bt);
+            pstore(bt);
+        }
+        wstore(0);
+        __syncthreads();
+        int cur = 0;
+        for (int c = c_begin; c < c_end; ++c) {
+            for (int tap = 0; tap < ntaps; ++tap) {
+                const bool last_tap = tap + 1 == ntaps;
+                const bool next_chunk = last_tap && (c + 1 < c_end);
+                const bool more = !last_tap || next_chunk;
+                if (more) wload(last_tap ? c + 1 : c, last_tap ? 0 : tap + 1);
+                if constexpr (PREFETCH) {
+                    if (next_chunk) pload(c + 1, 0);
+                }
+                const int ty = tap / p.TW, tx = tap - ty * p.TW;
+                const int toff = ((p.sy0 + ty * p.tstep - q.sy_min) * q.PW + (p.sx0 + tx * p.tstep - q.sx_min)) * LDK;
+                const float* Bb = Bs + cur * BN * LDK;
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+                    f32x4 a[WM], bb[WN];
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ps + abase[i] + toff + kg * 8);
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) bb[j] = *reinterpret_cast<const f32x4*>(Bb + (brow + 32 * j) * LDK + kg * 8 + ko);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < WM; ++i)
+#pragma unroll
+                            for (int j = 0; j < WN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], bb[j][e], acc[i][j], 0, 0, 0);
+                }
+                if (next_chunk) {
+                    __syncthreads();        // every wave is done with the current patch
+                    if constexpr (PREFETCH) {
+                        pstore(0);
+                    } else {
+#pragma unroll
+                        for (int bt = 0; bt < NBATCH; ++bt) {
+                            pload(c + 1, bt);
+                            pstore(bt);
+                        }
+                    }
+                }
+                if (more) wstore(cur ^ 1);
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+    }
+
+    // epilogue: row r -> output pixel (oy0 + r / TW, ox0 + r % TW)
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int oy = oy0 + row / TW_, ox = ox0 + row % TW_;
+            if (oy >= p.OH || ox >= p.OW) continue;
+            if (p.splits > 1) {
+                const size_t m = ((size_t)b * p.OH + oy) * p.OW + ox;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
+                    if (n < p.N) p.ws[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
+                }
+            } else {
+                const size_t pix = ((size_t)b * p.DH + (oy * p.ds + p.dy0)) * p.DW + (ox * p.ds + p.dx0);
+                const float rs = p.rowscale ? p.rowscale[pix] : 1.f;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
+                    if (n < p.N) {
+                        float v = acc[i][j][r];
+                        if (p.bias) v += p.bias[n];
+                        v = apply_act(v * rs, p.act, p.slope);
+                        float* d = p.dst + pix * p.N + n;
+                        if (p.accumulate) v += *d;
+                        *d = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int TH_, int TW_, int WAVES_M, int WAVES_N, int WM, int WN, int MAXPL>
+static int launch_pgemm_cfg(const IGemmParams& p, const PatchGeom& q, hipStream_t s) {
+    constexpr int BN = WAVES_N * WN * 32;
+    const size_t lds = ((size_t)2 * BN + (size_t)q.PH * q.PW) * 36 * sizeof(float);
+    static size_t attr_lds = 0;
+    auto kern = pgemm_kernel<TH_, TW_, WAVES_M, WAVES_N, WM, WN, MAXPL>;
+    if (lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            tg_set_error("pgemm: hipFuncSetAttribute(%zu) failed: %s", lds, hipGetErrorString(e));
+            return TG_ERR_LAUNCH;
+        }
+        attr_lds = lds;
+    }
+    dim3 grid(q.tiles_x * q.tiles_y * p.B * cdiv(p.N, BN), 1, p.splits);
+    {
+        const double by = 4.0 * ((double)p.B * p.IH * p.IW * p.C + (double)p.M + (double)p.N * p.Ktot + (double)p.M * p.N +
+                                 (p.amask ? (double)p.B * p.IH * p.IW : 0.0));
+        ProfScope ps(s, 0, 2.0 * p.M * (double)p.N * p.Ktot, by, p.M, p.N, p.Ktot, p.C, p.splits, 1000 + BN);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p, q);
+    }
+    TG_CHECK_LAUNCH("pgemm_kernel");
+    if (p.splits > 1) {
+        hipLaunchKernelGGL(igemm_splitk_epilogue, dim3(ew_grid((int64_t)p.M * p.N, 256)), dim3(256), 0, s, p);
+        TG_CHECK_LAUNCH("igemm_splitk_epilogue");
+    }
+    return TG_OK;
+}
+
+// Eligibility + planning of the patch kernel.  Returns true (and launches) when it applies.
+static bool try_pgemm(IGemmParams& p, size_t ws_floats_avail, hipStream_t s, int* rc) {
+    if (getenv("TG_NO_PGEMM")) return false;
+    if (p.ss != 1 || (p.C % 32) != 0 || p.TH < 1 || p.TW < 1 || p.TH > 4 || p.TW > 4) return false;
+    if (p.OW < 16 || p.OH < 8) return false;
+    const bool n64 = !(p.N >= 128 && p.N % 128 == 0);
+    if (n64 && p.N < 48) return false;                      // tiny N: dedicated kernels / v1
+    const int th = (n64 && p.OH >= 16) ? 16 : 8, tw = 16;
+    if (n64 && th != 16) return false;
+    PatchGeom q;
+    q.tiles_x = cdiv(p.OW, tw);
+    q.tiles_y = cdiv(p.OH, th);
+    const int sy_a = p.sy0, sy_b = p.sy0 + (p.TH - 1) * p.tstep, sx_a = p.sx0, sx_b = p.sx0 + (p.TW - 1) * p.tstep;
+    q.sy_min = sy_a < sy_b ? sy_a : sy_b;
+    q.sx_min = sx_a < sx_b ? sx_a : sx_b;
+    q.PH = th + p.TH - 1;
+    q.PW = tw + p.TW - 1;
+    p.Ktot = p.TH * p.TW * p.C;
+    p.nchunks = p.C / 32;
+    // split over channel chunks when the grid is small
+    const long tiles = (long)q.tiles_x * q.tiles_y * p.B * cdiv(p.N, n64 ? 64 : 128);
+    int splits = 1;
+    if (tiles < 384 && p.nchunks >= 4) {
+        splits = (int)((768 + tiles - 1) / tiles);
+        if (splits > p.nchunks / 2) splits = p.nchunks / 2;
+        if (splits > 32) splits = 32;
+        if (splits < 1) splits = 1;
+    }
+    while (splits > 1 && (size_t)splits * p.M * p.N > ws_floats_avail) --splits;
+    q.chunks_per_split = cdiv(p.nchunks, splits);
+    p.splits = cdiv(p.nchunks, q.chunks_per_split);
+    if (n64) *rc = launch_pgemm_cfg<16, 16, 4, 1, 2, 2, 12>(p, q, s);
+    else *rc = launch_pgemm_cfg<8, 16, 2, 2, 2, 2, 7>(p, q, s);
+    return true;
+}
+
 static int pick_bn(int N) { return N >= 128 && N % 128 == 0 ? 128 : (N > 32 ? 64 : 32); }
 
 // K-split so that small-M layers (enc5-7, dec7, dec6) still fill 256 CUs.
@@ -390,8 +725,12 @@ static void plan_splits(IGemmParams& p, size_t ws_floats_avail) {
     p.splits = p.T > 0 ? cdiv(p.T, p.steps_per_split) : 1;
 }
 
-static int launch_igemm(IGemmParams& p, hipStream_t s) {
+static int launch_igemm(IGemmParams& p, hipStream_t s, size_t ws_floats_avail = 0) {
     if (p.M <= 0 || p.N <= 0) return TG_OK;
+    {
+        int rc = TG_OK;
+        if (try_pgemm(p, ws_floats_avail, s, &rc)) return rc;
+    }
     const bool scalar = (p.C % 4) != 0;
     p.Ktot = p.TH * p.TW * p.C;
     p.nchunks = cdiv(p.C, 32);
@@ -451,7 +790,7 @@ extern "C" int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask
     p.Ktot = p.TH * p.TW * p.C; p.nchunks = cdiv(p.C, 32);
     p.T = (p.C % 4) ? cdiv(p.Ktot, 32) : p.TH * p.TW * p.nchunks;
     plan_splits(p, ws ? ws_bytes / sizeof(float) : 0);
-    return launch_igemm(p, (hipStream_t)stream);
+    return launch_igemm(p, (hipStream_t)stream, ws ? ws_bytes / sizeof(float) : 0);
 }
 
 // ---- dgrad ---------------------------------------------------------------------------------------
@@ -517,7 +856,7 @@ extern "C" int tg_conv_dgrad(const TgConv* g, const float* dy, const float* w, c
             p.Ktot = p.TH * p.TW * p.C; p.nchunks = cdiv(p.C, 32);
             p.T = (p.C % 4) ? cdiv(p.Ktot, 32) : p.TH * p.TW * p.nchunks;
             plan_splits(p, ws2_floats);
-            rc = launch_igemm(p, s);
+            rc = launch_igemm(p, s, ws2_floats);
             if (rc) return rc;
         }
     }
@@ -534,6 +873,7 @@ struct WgradParams {
     float* out;  // [splits][Cout][Ktot]
     int B, H, W, C, Ho, Wo, Cout, k, stride, pad;
     int Mpix, Ktot, T, splits, steps_per_split;
+    int nx, ny;   // N' tiles, Cout tiles (grid is launched flat: nx*ny*splits workgroups)
 };
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR_A, bool SCALAR_B>
@@ -550,8 +890,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int n0 = blockIdx.x * BN, c0m = blockIdx.y * BM;
-    const int t_begin = blockIdx.z * p.steps_per_split;
+    // flat grid, XCD-remapped: the N'/Cout tiles of one pixel range (split) run on one XCD and share its L2
+    const int work = xcd_remap(blockIdx.x, p.nx * p.ny * p.splits);
+    const int bz = work / (p.nx * p.ny);
+    const int bxy = work - bz * (p.nx * p.ny);
+    const int n0 = (bxy % p.nx) * BN, c0m = (bxy / p.nx) * BM;
+    const int t_begin = bz * p.steps_per_split;
     const int t_end = min(p.T, t_begin + p.steps_per_split);
 
     // B' columns owned by this thread: n = n0 + 4*(tid&31) + e  ->  (tap, c), fixed over the K loop
@@ -571,6 +915,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     f32x4 ra[SCALAR_A ? 1 : A_V];
     float ras[SCALAR_A ? A_S : 1];
     f32x4 rbv[B_V];
+
+    // (b, oy, ox) of the B' rows this thread gathers, for the NEXT K step; advanced by 32 pixels per step
+    int pb[B_V], py[B_V], px[B_V];
+#pragma unroll
+    for (int i = 0; i < B_V; ++i) {
+        int m = t_begin * BK + (tid >> 5) + 8 * i;
+        px[i] = m % p.Wo;
+        int tt = m / p.Wo;
+        py[i] = tt % p.Ho;
+        pb[i] = tt / p.Ho;
+    }
 
     auto gload = [&](int t) {
         const int mbase = t * BK;
@@ -602,10 +957,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
             int m = mbase + krow;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (m < p.Mpix) {
-                int ox = m % p.Wo;
-                int tt = m / p.Wo;
-                int oy = tt % p.Ho;
-                int b = tt / p.Ho;
+                const int ox = px[i], oy = py[i], b = pb[i];
                 if constexpr (!SCALAR_B) {
                     int iy = oy * p.stride + bky[0], ix = ox * p.stride + bkx[0];
                     if (bv[0] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
@@ -627,6 +979,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
                 }
             }
             rbv[i] = v;
+            // advance this row by BK pixels for the next step
+            px[i] += BK;
+            while (px[i] >= p.Wo) {
+                px[i] -= p.Wo;
+                if (++py[i] == p.Ho) { py[i] = 0; ++pb[i]; }
+            }
         }
     };
     auto sstore = [&](int buf) {
@@ -694,7 +1052,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         }
     }
 
-    float* out = p.out + (size_t)blockIdx.z * p.Cout * p.Ktot;
+    float* out = p.out + (size_t)bz * p.Cout * p.Ktot;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -734,12 +1092,15 @@ static int launch_wgrad_cfg(const WgradParams& p, hipStream_t s) {
         }
         attr_done = true;
     }
-    dim3 grid(cdiv(p.Ktot, BN), cdiv(p.Cout, BM), p.splits);
+    WgradParams pp = p;
+    pp.nx = cdiv(p.Ktot, BN);
+    pp.ny = cdiv(p.Cout, BM);
+    dim3 grid(pp.nx * pp.ny * p.splits);
     {
         const double by = 4.0 * ((double)p.B * p.H * p.W * p.C + (double)p.Mpix * p.Cout + (double)p.Cout * p.Ktot +
                                  (double)p.Mpix + (p.amask ? (double)p.B * p.H * p.W : 0.0));
         ProfScope ps(s, 1, 2.0 * p.Mpix * (double)p.Cout * p.Ktot, by, p.Cout, p.Ktot, p.Mpix, p.C, p.splits, BM);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, pp);
     }
     TG_CHECK_LAUNCH("wgrad_kernel");
     return TG_OK;

@@ -431,9 +431,9 @@ __device__ __forceinline__ Lerp lerp_src(int dst, int n) {
 }
 
 template <int V>  // V = 4 (float4 over channels) or 1
-__global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict__ up, const float* __restrict__ skip, int B,
-                                                        int h, int w, int Cu, int H, int W, int Cs, int offy, int offx,
-                                                        float* __restrict__ out) {
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict__ up, const float* __restrict__ skip,
+                                                        const float* __restrict__ omask, int B, int h, int w, int Cu, int H,
+                                                        int W, int Cs, int offy, int offx, float* __restrict__ out) {
     const int Ct = Cu + Cs;
     const int cv = Ct / V;
     const int64_t total = (int64_t)B * H * W * cv;
@@ -465,22 +465,23 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict_
                 }
             }
         }
+        const float mk = omask ? omask[pix] : 1.f;
 #pragma unroll
-        for (int e = 0; e < V; ++e) out[pix * Ct + c + e] = o[e];
+        for (int e = 0; e < V; ++e) out[pix * Ct + c + e] = o[e] * mk;
     }
 }
-extern "C" int tg_upcat_fwd(const float* up, const float* skip, int B, int h, int w, int Cu, int H, int W, int Cs, float* out,
-                            tg_stream_t stream) {
+extern "C" int tg_upcat_fwd(const float* up, const float* skip, const float* out_mask, int B, int h, int w, int Cu, int H, int W,
+                            int Cs, float* out, tg_stream_t stream) {
     TG_REQUIRE(up && out && B > 0 && h > 0 && w > 0 && Cu > 0 && H > 0 && W > 0 && Cs >= 0, "tg_upcat_fwd: bad arguments");
     TG_REQUIRE(Cs == 0 || skip, "tg_upcat_fwd: skip is NULL but Cs > 0");
     const int offy = floordiv2(H - 2 * h), offx = floordiv2(W - 2 * w);
     const int Ct = Cu + Cs;
     if (Cu % 4 == 0 && Cs % 4 == 0) {
         hipLaunchKernelGGL((upcat_fwd_kernel<4>), dim3(ew_grid((int64_t)B * H * W * (Ct / 4), 256)), dim3(256), 0, S(stream), up,
-                           skip, B, h, w, Cu, H, W, Cs, offy, offx, out);
+                           skip, out_mask, B, h, w, Cu, H, W, Cs, offy, offx, out);
     } else {
         hipLaunchKernelGGL((upcat_fwd_kernel<1>), dim3(ew_grid((int64_t)B * H * W * Ct, 256)), dim3(256), 0, S(stream), up, skip,
-                           B, h, w, Cu, H, W, Cs, offy, offx, out);
+                           out_mask, B, h, w, Cu, H, W, Cs, offy, offx, out);
     }
     TG_CHECK_LAUNCH("upcat_fwd_kernel");
     return TG_OK;

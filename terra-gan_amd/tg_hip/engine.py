@@ -30,16 +30,19 @@ VGG_TRUNK = [0, 2, "M", 5, 7, "M", 10, 12, 14]
 # --------------------------------------------------------------------------------------------------
 # partial-conv layer (conv -> *ratio -> BN -> ReLU)
 # --------------------------------------------------------------------------------------------------
-def _pconv_fwd(P, name, k, s, p, x, in_mask, ratio, training):
+def _pconv_fwd(P, name, k, s, p, x, in_mask, ratio, training, premasked=False):
+    """premasked: x already holds input*mask (the decoder concat is written that way), so the conv and its
+    wgrad skip the mask prologue; dgrad still applies the mask."""
     y = O.conv_fwd(x, P[f"{name}.input_conv.weight"], P[f"{name}.input_conv.bias"].detach(), k, s, p,
-                   in_mask=in_mask, ratio=ratio)
+                   in_mask=None if premasked else in_mask, ratio=ratio)
     if training:
         mean, rstd = O.bn_stats(y, P[f"{name}.bn.running_mean"], P[f"{name}.bn.running_var"],
                                 P[f"{name}.bn.num_batches_tracked"])
     else:
         mean, rstd = O.bn_eval_stats(P[f"{name}.bn.running_mean"], P[f"{name}.bn.running_var"])
     a = O.bn_act_fwd(y, mean, rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU)
-    return a, NS(name=name, k=k, s=s, p=p, x=x, in_mask=in_mask, ratio=ratio, y=y, mean=mean, rstd=rstd)
+    return a, NS(name=name, k=k, s=s, p=p, x=x, in_mask=in_mask, ratio=ratio, y=y, mean=mean, rstd=rstd,
+                 premasked=premasked)
 
 
 def _pconv_bwd(P, c, da, grads, dx_out=None, want_dx=True):
@@ -47,7 +50,8 @@ def _pconv_bwd(P, c, da, grads, dx_out=None, want_dx=True):
     name = c.name
     dyr, dgamma, dbeta = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU,
                                       ratio=c.ratio)
-    dw, db = O.conv_wgrad(c.x, dyr, P[f"{name}.input_conv.weight"], c.k, c.s, c.p, in_mask=c.in_mask)
+    dw, db = O.conv_wgrad(c.x, dyr, P[f"{name}.input_conv.weight"], c.k, c.s, c.p,
+                          in_mask=None if getattr(c, "premasked", False) else c.in_mask)
     grads[f"{name}.input_conv.weight"], grads[f"{name}.input_conv.bias"] = dw, db
     grads[f"{name}.bn.weight"], grads[f"{name}.bn.bias"] = dgamma, dbeta
     if not want_dx:
@@ -85,8 +89,8 @@ def generator_forward(P, x, mask, training=True):
         skip = e[6 - i] if i < 6 else None
         Hs, Ws = (skip.shape[1], skip.shape[2]) if skip is not None else (H, W)
         up_shape = tuple(d.shape)
-        cat = O.upcat_fwd(d, skip, Hs, Ws)
-        d, c = _pconv_fwd(P, name, k, s, p, cat, dmasks[i], dr[i], training)
+        cat = O.upcat_fwd(d, skip, Hs, Ws, out_mask=dmasks[i])       # = merged_feature * merged_mask
+        d, c = _pconv_fwd(P, name, k, s, p, cat, dmasks[i], dr[i], training, premasked=True)
         c.up_shape = up_shape
         dec_ctx.append(c)
     logits = O.conv_fwd(d, P["final.weight"], P["final.bias"].detach(), 3, 1, 1)      # generator.py:29,56

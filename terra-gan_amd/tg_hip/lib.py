@@ -41,7 +41,7 @@ SIGNATURES = {
     "tg_bn_act_fwd": (I, [P, I64, I, P, P, P, P, I, F, P, P]),
     "tg_bn_act_bwd": (I, [P, P, I64, I, P, P, P, P, I, F, P, P, P, P, P, SZ, P]),
     "tg_act_bwd": (I, [P, P, I64, I, I, F, P, P, P]),
-    "tg_upcat_fwd": (I, [P, P, I, I, I, I, I, I, I, P, P]),
+    "tg_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P]),
     "tg_upcat_bwd": (I, [P, I, I, I, I, I, I, I, P, P, P]),
     "tg_sigmoid_composite_fwd": (I, [P, P, P, I64, P, P]),
     "tg_sigmoid_composite_bwd": (I, [P, P, P, I64, P, P, P]),

@@ -201,12 +201,12 @@ def act_bwd(dout, out, act, slope=0.0, ratio=None, inplace=True):
     return din
 
 
-def upcat_fwd(up, skip, H, W):
-    _chk(up, "up"); _chk(skip, "skip")
+def upcat_fwd(up, skip, H, W, out_mask=None):
+    _chk(up, "up"); _chk(skip, "skip"); _chk(out_mask, "out_mask")
     B, h, w, Cu = up.shape
     Cs = 0 if skip is None else skip.shape[3]
     out = empty(B, H, W, Cu + Cs, like=up)
-    L.check(_lib().tg_upcat_fwd(_p(up), _p(skip), B, h, w, Cu, H, W, Cs, _p(out), _stream()), "tg_upcat_fwd")
+    L.check(_lib().tg_upcat_fwd(_p(up), _p(skip), _p(out_mask), B, h, w, Cu, H, W, Cs, _p(out), _stream()), "tg_upcat_fwd")
     return out
 
 

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the MFMA conv kernels on the layer shapes of the 256x256 / B=16 train step.
+Prints per-shape TFLOP/s measured with the library's own hipEvent hooks (tg_prof_*).
+    python tools/conv_bench.py [--reps 5] [--only dec1,vgg1_2]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "terra-gan_amd"))
+import torch  # noqa: E402
+
+from tg_hip import lib as L  # noqa: E402
+from tg_hip import ops as O  # noqa: E402
+
+# name, B, H, W, Cin, Cout, k, s, p, masked
+SHAPES = [
+    ("vgg1_2", 32, 256, 256, 64, 64, 3, 1, 1, False),
+    ("dec1", 16, 256, 256, 64, 64, 3, 1, 1, True),
+    ("dec2", 16, 128, 128, 192, 64, 3, 1, 1, True),
+    ("dec3", 16, 64, 64, 384, 128, 3, 1, 1, True),
+    ("dec4", 16, 32, 32, 768, 256, 3, 1, 1, True),
+    ("dec5", 16, 16, 16, 1024, 512, 3, 1, 1, True),
+    ("vgg2_2", 32, 128, 128, 128, 128, 3, 1, 1, False),
+    ("vgg3_2", 32, 64, 64, 256, 256, 3, 1, 1, False),
+    ("enc2", 16, 128, 128, 64, 128, 5, 2, 2, True),
+    ("enc3", 16, 64, 64, 128, 256, 5, 2, 2, True),
+    ("enc5", 16, 16, 16, 512, 512, 3, 2, 1, True),
+    ("d1", 16, 128, 128, 64, 128, 4, 2, 1, False),
+    ("d3", 16, 32, 32, 256, 512, 4, 2, 1, False),
+    ("final", 16, 256, 256, 64, 1, 3, 1, 1, False),
+    ("enc1", 16, 256, 256, 1, 64, 7, 2, 3, True),
+]
+
+
+def summary(lib, kind):
+    ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+    lib.tg_prof_summary(kind, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
+    return ms.value, n.value, fl.value, by.value
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    only = set(filter(None, args.only.split(",")))
+    print(f"{'layer':8s} {'op':6s} {'ms':>8s} {'TF':>7s} {'algGB/s':>8s}")
+    for name, B, H, W, Cin, Cout, k, s, p, masked in SHAPES:
+        if only and name not in only:
+            continue
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+        w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.05).contiguous(memory_format=torch.channels_last).to(dev)
+        bias = torch.randn(Cout, generator=g).to(dev)
+        m = (torch.rand(B, H, W, generator=g) > 0.2).float().to(dev) if masked else None
+        ratio = None
+        if masked:
+            _, ratio = O.mask_update(m, k, s, p)
+        y = O.conv_fwd(x, w, bias, k, s, p, in_mask=m, ratio=ratio)
+        dy = torch.randn(y.shape, generator=g).to(dev)
+        for op in ("fwd", "dgrad", "wgrad"):
+            fn = {"fwd": lambda: O.conv_fwd(x, w, bias, k, s, p, in_mask=m, ratio=ratio),
+                  "dgrad": lambda: O.conv_dgrad(dy, w, tuple(x.shape), k, s, p, in_mask=m),
+                  "wgrad": lambda: O.conv_wgrad(x, dy, w, k, s, p, in_mask=m)}[op]
+            fn()
+            torch.cuda.synchronize()
+            lib.tg_prof_enable(1)
+            for _ in range(args.reps):
+                fn()
+            torch.cuda.synchronize()
+            lib.tg_prof_enable(0)
+            ms0, n0, fl0, by0 = summary(lib, 0)
+            ms1, n1, fl1, by1 = summary(lib, 1)
+            ms, fl, by = ms0 + ms1, fl0 + fl1, by0 + by1
+            print(f"{name:8s} {op:6s} {ms / args.reps:8.3f} {fl / ms / 1e9 if ms else 0:7.1f} {by / ms / 1e6 if ms else 0:8.1f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -143,6 +143,7 @@ def main():
             lib.tg_prof_dump(args.prof_dump.encode())
         ms0, n0, fl0, by0 = prof_summary(lib, 0)
         ms1, n1, fl1, by1 = prof_summary(lib, 1)
+        ms2, n2, fl2, by2 = prof_summary(lib, 2)
         ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": "igemm_kernel (fp32 MFMA implicit-GEMM conv fwd/dgrad)",
                     "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -152,7 +153,9 @@ def main():
                     "hbm_alg_GBps": round(by0 / (ms0 * 1e-3) / 1e9, 1) if ms0 > 0 else 0.0,
                     "wgrad": {"achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else 0.0,
                               "launches_per_step": n1 // 2, "kernel_ms_per_step": round(ms1 / 2, 3),
-                              "hbm_alg_GBps": round(by1 / (ms1 * 1e-3) / 1e9, 1) if ms1 > 0 else 0.0}}
+                              "hbm_alg_GBps": round(by1 / (ms1 * 1e-3) / 1e9, 1) if ms1 > 0 else 0.0},
+                    "smallconv_1ch": {"bound": "hbm", "launches_per_step": n2 // 2, "kernel_ms_per_step": round(ms2 / 2, 3),
+                                      "hbm_alg_GBps": round(by2 / (ms2 * 1e-3) / 1e9, 1) if ms2 > 0 else 0.0}}
     if world > 1:
         dist.barrier()
 

@@ -103,26 +103,7 @@ extern "C" int tg_prof_summary(int kind, double* total_ms, int64_t* launches, do
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad: gathered-row A operand, dense K-contiguous B operand
 // ------------------------------------------------------------------------------------------------
-struct IGemmParams {
-    const float* src;       // A source, NHWC [B][IH][IW][C]
-    const float* amask;     // optional [B][IH][IW]: A row scale at the SOURCE pixel (x (.) mask)
-    const float* wmat;      // B matrix [N][Kfull], K-contiguous, K index = tapidx*C + c
-    const float* bias;      // optional [N]
-    const float* rowscale;  // optional, indexed by DESTINATION pixel (ratio / dgrad mask)
-    float* dst;             // NHWC [B][DH][DW][N]
-    float* ws;              // split-K slabs [splits][M][N] when splits > 1
-    int B, IH, IW, C;
-    int OH, OW, N, M;       // output grid of this launch, M = B*OH*OW
-    int DH, DW, ds, dy0, dx0;           // grid point (oy,ox) -> dst pixel (oy*ds+dy0, ox*ds+dx0)
-    int TH, TW, ss, tstep, sy0, sx0;    // tap (ty,tx) -> src pixel (oy*ss+sy0+ty*tstep, ...)
-    int KW, kstep, ky0, kx0;            // tap (ty,tx) -> weight tap (ky0+ty*kstep)*KW + kx0+tx*kstep
-    int Kfull, Ktot;        // wmat row length; K elements walked by this launch (TH*TW*C)
-    int nchunks, T;         // ceil(C/32); number of 32-deep K steps
-    int splits, steps_per_split;
-    int act;
-    float slope;
-    int accumulate;
-};
+#include "igemm_params.h"
 
 // XCD-aware work remap (bijective): hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
 // ids b and b+8 share an L2.  Map id -> work index such that each XCD gets a CONTIGUOUS range of work items;
@@ -727,6 +708,13 @@ static void plan_splits(IGemmParams& p, size_t ws_floats_avail) {
 
 static int launch_igemm(IGemmParams& p, hipStream_t s, size_t ws_floats_avail = 0) {
     if (p.M <= 0 || p.N <= 0) return TG_OK;
+    if (smallconv_fwd_applies(p)) {          // 1-channel side: HBM-bound dedicated kernels (smallconv.hip)
+        p.splits = 1;
+        p.Ktot = p.TH * p.TW * p.C;
+        const double by = 4.0 * ((double)p.B * p.IH * p.IW * p.C + (double)p.M * p.N + (double)p.N * p.Ktot);
+        ProfScope ps(s, 2, 2.0 * p.M * (double)p.N * p.Ktot, by, p.M, p.N, p.Ktot, p.C, 1, 2000);
+        return smallconv_fwd_launch(p, s);
+    }
     {
         int rc = TG_OK;
         if (try_pgemm(p, ws_floats_avail, s, &rc)) return rc;
@@ -866,15 +854,6 @@ extern "C" int tg_conv_dgrad(const TgConv* g, const float* dy, const float* w, c
 // ------------------------------------------------------------------------------------------------
 // wgrad: dW[cout][(tap,c)] = sum over pixels; both operands pixel-major ([k][m] LDS images, ds_read_b32)
 // ------------------------------------------------------------------------------------------------
-struct WgradParams {
-    const float* x;
-    const float* amask;
-    const float* dy;
-    float* out;  // [splits][Cout][Ktot]
-    int B, H, W, C, Ho, Wo, Cout, k, stride, pad;
-    int Mpix, Ktot, T, splits, steps_per_split;
-    int nx, ny;   // N' tiles, Cout tiles (grid is launched flat: nx*ny*splits workgroups)
-};
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR_A, bool SCALAR_B>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
@@ -1133,6 +1112,12 @@ extern "C" size_t tg_conv_wgrad_ws_bytes(const TgConv* g) {
     int splits, sps, T;
     wgrad_plan(g, &splits, &sps, &T);
     size_t slabs = align_up((size_t)splits * g->Cout * g->k * g->k * g->Cin, 64);
+    WgradParams sp = {};
+    sp.C = g->Cin; sp.Cout = g->Cout; sp.k = g->k; sp.Mpix = g->B * g->Ho * g->Wo;
+    if (smallconv_wgrad_applies(sp)) {
+        size_t alt = align_up(smallconv_wgrad_ws_floats(sp), 64);
+        if (alt > slabs) slabs = alt;
+    }
     return (slabs + tg_colsum_ws_floats((int64_t)g->B * g->Ho * g->Wo, g->Cout)) * sizeof(float);
 }
 
@@ -1151,6 +1136,20 @@ extern "C" int tg_conv_wgrad(const TgConv* g, const float* x, const float* in_ma
     p.k = g->k; p.stride = g->stride; p.pad = g->pad;
     p.Mpix = g->B * g->Ho * g->Wo; p.Ktot = g->k * g->k * g->Cin;
     wgrad_plan(g, &p.splits, &p.steps_per_split, &p.T);
+    if (smallconv_wgrad_applies(p)) {
+        {
+            const double by = 4.0 * ((double)p.B * p.H * p.W * p.C + (double)p.Mpix * p.Cout + (double)p.Cout * p.Ktot);
+            ProfScope ps(s, 2, 2.0 * p.Mpix * (double)p.Cout * p.Ktot, by, p.Cout, p.Ktot, p.Mpix, p.C, 1, 2001);
+            rc = smallconv_wgrad_launch(p, dw, ws, s);
+        }
+        if (rc) return rc;
+        if (db) {
+            size_t used = align_up(smallconv_wgrad_ws_floats(p), 64);
+            rc = tg_colsum_launch(dy, (int64_t)p.Mpix, g->Cout, db, ws + used, s);
+            if (rc) return rc;
+        }
+        return TG_OK;
+    }
     p.out = p.splits > 1 ? ws : dw;
     const int bm = wgrad_bm(g);
     const bool sb = (g->Cin % 4) != 0;

@@ -1,0 +1,41 @@
+// Parameter blocks shared by the MFMA conv kernels (igemm.hip) and the small-channel kernels (smallconv.hip).
+#pragma once
+#include "common.h"
+
+struct IGemmParams {
+    const float* src;       // A source, NHWC [B][IH][IW][C]
+    const float* amask;     // optional [B][IH][IW]: A row scale at the SOURCE pixel (x (.) mask)
+    const float* wmat;      // B matrix [N][Kfull], K-contiguous, K index = tapidx*C + c
+    const float* bias;      // optional [N]
+    const float* rowscale;  // optional, indexed by DESTINATION pixel (ratio / dgrad mask)
+    float* dst;             // NHWC [B][DH][DW][N]
+    float* ws;              // split-K slabs [splits][M][N] when splits > 1
+    int B, IH, IW, C;
+    int OH, OW, N, M;       // output grid of this launch, M = B*OH*OW
+    int DH, DW, ds, dy0, dx0;           // grid point (oy,ox) -> dst pixel (oy*ds+dy0, ox*ds+dx0)
+    int TH, TW, ss, tstep, sy0, sx0;    // tap (ty,tx) -> src pixel (oy*ss+sy0+ty*tstep, ...)
+    int KW, kstep, ky0, kx0;            // tap (ty,tx) -> weight tap (ky0+ty*kstep)*KW + kx0+tx*kstep
+    int Kfull, Ktot;        // wmat row length; K elements walked by this launch (TH*TW*C)
+    int nchunks, T;         // ceil(C/32); number of 32-deep K steps
+    int splits, steps_per_split;
+    int act;
+    float slope;
+    int accumulate;
+};
+
+struct WgradParams {
+    const float* x;
+    const float* amask;
+    const float* dy;
+    float* out;  // [splits][Cout][Ktot]
+    int B, H, W, C, Ho, Wo, Cout, k, stride, pad;
+    int Mpix, Ktot, T, splits, steps_per_split;
+    int nx, ny;   // N' tiles, Cout tiles (grid is launched flat: nx*ny*splits workgroups)
+};
+
+// smallconv.hip: bandwidth-bound special cases that would waste >95% of an MFMA tile
+bool smallconv_fwd_applies(const IGemmParams& p);             // C == 1 -> N%64 == 0, or N == 1 <- C%64 == 0
+int smallconv_fwd_launch(const IGemmParams& p, hipStream_t s);
+bool smallconv_wgrad_applies(const WgradParams& p);
+size_t smallconv_wgrad_ws_floats(const WgradParams& p);
+int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream_t s);

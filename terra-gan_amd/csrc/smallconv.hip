@@ -1,0 +1,377 @@
+// Bandwidth-bound convolutions with a single input or a single output channel (enc1, D conv0, VGG conv1_1,
+// `final`, D conv4 and their gradients).  As GEMMs they have N or K of 1 and would use <5 % of an MFMA tile.
+// Here a wavefront's 64 lanes ARE 64 channels of the wide side, so every global access to the wide tensor is
+// one coalesced 256-byte row.
+//   * 1 -> N channels (c1conv / c1wgrad): the 1-channel source patch of a 16x16 output tile is staged in LDS
+//     once (zero halo, mask pre-multiplied), so the tap loop is branch-free: one broadcast ds_read + one FMA.
+//   * C -> 1 channel (to1conv / to1wgrad): tap loops are compile-time unrolled and predicated (clamped address,
+//     0/1 factor) so all tap loads of 4 pixels are in flight together; the reduction over channels shares one
+//     7-shuffle butterfly between 4 pixels.
+#include <stdlib.h>
+
+#include "igemm_params.h"
+
+__device__ __forceinline__ int weight_tap(const IGemmParams& p, int ty, int tx) {
+    return (p.ky0 + ty * p.kstep) * p.KW + (p.kx0 + tx * p.kstep);
+}
+__device__ __forceinline__ size_t out_pixel(const IGemmParams& p, int b, int oy, int ox) {
+    return ((size_t)b * p.DH + (oy * p.ds + p.dy0)) * p.DW + (ox * p.ds + p.dx0);
+}
+
+constexpr int C1_T = 16;   // output tile edge of the 1-channel-source kernels
+
+struct C1Geom {
+    int tiles_x, tiles_y, PH, PW, sy_min, sx_min;
+};
+
+// stage the [PH][PW] source patch of tile (b, oy0, ox0): zero outside the image, mask pre-multiplied
+__device__ __forceinline__ void c1_stage_patch(const float* __restrict__ src, const float* __restrict__ amask, float* patch,
+                                               int b, int py0, int px0, int PH, int PW, int IH, int IW) {
+    for (int i = threadIdx.x; i < PH * PW; i += 256) {
+        const int py = i / PW, px = i - py * PW;
+        const int iy = py0 + py, ix = px0 + px;
+        float v = 0.f;
+        if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) {
+            const size_t pix = ((size_t)b * IH + iy) * IW + ix;
+            v = src[pix];
+            if (amask) v *= amask[pix];
+        }
+        patch[i] = v;
+    }
+}
+
+// ---- 1 source channel -> N channels (N % 64 == 0): lane = output channel ----------------------------------
+template <int TH_, int TW_>   // taps (0,0 = runtime)
+__global__ __launch_bounds__(256) void c1conv_kernel(const IGemmParams p, const C1Geom q) {
+    extern __shared__ float sm[];
+    float* patch = sm;                 // [PH*PW]
+    float* wl = sm + q.PH * q.PW;      // [taps][64] (runtime-tap variant only)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.y * 64 + lane;
+    const int TH = TH_ ? TH_ : p.TH, TW = TW_ ? TW_ : p.TW;
+    int tile = blockIdx.x;
+    const int txi = tile % q.tiles_x;
+    tile /= q.tiles_x;
+    const int tyi = tile % q.tiles_y, b = tile / q.tiles_y;
+    const int oy0 = tyi * C1_T, ox0 = txi * C1_T;
+    c1_stage_patch(p.src, p.amask, patch, b, oy0 * p.ss + q.sy_min, ox0 * p.ss + q.sx_min, q.PH, q.PW, p.IH, p.IW);
+    constexpr int NT = TH_ * TW_ > 0 ? TH_ * TW_ : 1;
+    float w[NT];
+    if constexpr (TH_ > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[t] = p.wmat[(size_t)n * p.Kfull + weight_tap(p, t / TW_, t % TW_)];
+    } else {
+        for (int i = threadIdx.x; i < TH * TW * 64; i += 256)
+            wl[i] = p.wmat[(size_t)(blockIdx.y * 64 + (i & 63)) * p.Kfull + weight_tap(p, (i >> 6) / TW, (i >> 6) % TW)];
+    }
+    __syncthreads();
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    const int oyy = p.sy0 - q.sy_min, oxx = p.sx0 - q.sx_min;
+    // each wave owns 4 rows of the 16x16 tile
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        const int ty_o = wave * 4 + r;
+        const int oy = oy0 + ty_o;
+        if (oy >= p.OH) break;
+#pragma unroll 4
+        for (int tx_o = 0; tx_o < C1_T; ++tx_o) {
+            const int ox = ox0 + tx_o;
+            if (ox >= p.OW) break;
+            const float* pb = patch + (ty_o * p.ss + oyy) * q.PW + tx_o * p.ss + oxx;
+            float acc = 0.f;
+            if constexpr (TH_ > 0) {
+#pragma unroll
+                for (int ty = 0; ty < TH_; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < TW_; ++tx) acc = fmaf(pb[ty * p.tstep * q.PW + tx * p.tstep], w[ty * TW_ + tx], acc);
+            } else {
+                for (int ty = 0; ty < TH; ++ty)
+                    for (int tx = 0; tx < TW; ++tx)
+                        acc = fmaf(pb[ty * p.tstep * q.PW + tx * p.tstep], wl[(ty * TW + tx) * 64 + lane], acc);
+            }
+            const size_t opix = out_pixel(p, b, oy, ox);
+            float v = acc + bias;
+            if (p.rowscale) v *= p.rowscale[opix];
+            v = apply_act(v, p.act, p.slope);
+            float* d = p.dst + opix * p.N + n;
+            if (p.accumulate) v += *d;
+            *d = v;
+        }
+    }
+}
+
+// ---- 64 channels -> 1 channel: lane = (pixel of a 4-pixel row segment, channel quad) --------------------------
+// Each lane loads float4 (4 channels), so one wave instruction fetches the full 256-B rows of 4 neighbouring
+// pixels; the row base is wave-uniform (scalar ALU), the tap loops are unrolled and predicated, and the channel
+// reduction is a 4-step shuffle inside each 16-lane group.  Requires OW % 4 == 0.
+template <int TH_, int TW_>
+__global__ __launch_bounds__(256) void to1conv64_kernel(const IGemmParams p) {
+    constexpr int NT = TH_ * TW_;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = lane >> 4, cq = lane & 15;
+    f32x4 w[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        w[t] = *reinterpret_cast<const f32x4*>(p.wmat + (size_t)weight_tap(p, t / TW_, t % TW_) * 64 + 4 * cq);
+    const float bias = p.bias ? p.bias[0] : 0.f;
+    const int quads = p.M >> 2;
+    const int waves_total = gridDim.x * 4;
+    for (int q0 = blockIdx.x * 4 + wave; q0 < quads; q0 += waves_total) {
+        const int q = __builtin_amdgcn_readfirstlane(q0);
+        const int m0 = 4 * q;
+        const int ox0 = m0 % p.OW;
+        const int t2 = m0 / p.OW;
+        const int oy = t2 % p.OH, b = t2 / p.OH;
+        const int ox = ox0 + e;
+        float acc = 0.f;
+#pragma unroll
+        for (int ty = 0; ty < TH_; ++ty) {
+            const int iy = oy * p.ss + p.sy0 + ty * p.tstep;
+            const bool vy = iy >= 0 && iy < p.IH;
+            const size_t rowbase = ((size_t)b * p.IH + min(max(iy, 0), p.IH - 1)) * p.IW;
+#pragma unroll
+            for (int tx = 0; tx < TW_; ++tx) {
+                const int ix = ox * p.ss + p.sx0 + tx * p.tstep;
+                const bool vx = ix >= 0 && ix < p.IW;
+                const size_t pix = rowbase + min(max(ix, 0), p.IW - 1);
+                float f = (vy && vx) ? 1.f : 0.f;
+                if (p.amask) f *= p.amask[pix];
+                const f32x4 x = *reinterpret_cast<const f32x4*>(p.src + pix * 64 + 4 * cq);
+                const f32x4 ww = w[ty * TW_ + tx];
+                acc = fmaf(f, x[0] * ww[0] + x[1] * ww[1] + x[2] * ww[2] + x[3] * ww[3], acc);
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (cq == 0) {
+            const size_t opix = out_pixel(p, b, oy, ox);
+            float r = acc + bias;
+            if (p.rowscale) r *= p.rowscale[opix];
+            r = apply_act(r, p.act, p.slope);
+            if (p.accumulate) r += p.dst[opix];
+            p.dst[opix] = r;
+        }
+    }
+}
+
+static bool to1_cfg_ok(int th, int tw) {
+    return (th == 3 && tw == 3) || (th == 2 && tw == 2) || (th == 4 && tw == 4) || (th == 1 && tw == 1) || (th == 2 && tw == 1) ||
+           (th == 1 && tw == 2);
+}
+
+bool smallconv_fwd_applies(const IGemmParams& p) {
+    if (getenv("TG_NO_SMALLCONV")) return false;
+    const int taps = p.TH * p.TW;
+    if (p.C == 1 && p.N >= 64 && p.N % 64 == 0 && taps >= 1 && taps <= 64) return true;
+    if (p.N == 1 && p.C == 64 && (p.OW % 4) == 0 && to1_cfg_ok(p.TH, p.TW)) return true;
+    return false;
+}
+
+#define TO1_CASE(TH_, TW_)                                                                           \
+    if (p.TH == TH_ && p.TW == TW_) {                                                                \
+        hipLaunchKernelGGL((to1conv64_kernel<TH_, TW_>), dim3(blocks), dim3(256), 0, s, p);          \
+        TG_CHECK_LAUNCH("to1conv64_kernel");                                                         \
+        return TG_OK;                                                                                \
+    }
+
+int smallconv_fwd_launch(const IGemmParams& p, hipStream_t s) {
+    if (p.C == 1) {
+        C1Geom q;
+        q.tiles_x = cdiv(p.OW, C1_T);
+        q.tiles_y = cdiv(p.OH, C1_T);
+        const int sy_b = p.sy0 + (p.TH - 1) * p.tstep, sx_b = p.sx0 + (p.TW - 1) * p.tstep;
+        q.sy_min = p.sy0 < sy_b ? p.sy0 : sy_b;
+        q.sx_min = p.sx0 < sx_b ? p.sx0 : sx_b;
+        q.PH = (C1_T - 1) * p.ss + (p.TH - 1) + 1;
+        q.PW = (C1_T - 1) * p.ss + (p.TW - 1) + 1;
+        dim3 grid(q.tiles_x * q.tiles_y * p.B, p.N / 64);
+        const size_t lds = ((size_t)q.PH * q.PW + (size_t)p.TH * p.TW * 64) * sizeof(float);
+        if (p.TH == 7 && p.TW == 7) hipLaunchKernelGGL((c1conv_kernel<7, 7>), grid, dim3(256), lds, s, p, q);
+        else if (p.TH == 4 && p.TW == 4) hipLaunchKernelGGL((c1conv_kernel<4, 4>), grid, dim3(256), lds, s, p, q);
+        else if (p.TH == 3 && p.TW == 3) hipLaunchKernelGGL((c1conv_kernel<3, 3>), grid, dim3(256), lds, s, p, q);
+        else hipLaunchKernelGGL((c1conv_kernel<0, 0>), grid, dim3(256), lds, s, p, q);
+        TG_CHECK_LAUNCH("c1conv_kernel");
+        return TG_OK;
+    }
+    int blocks = cdiv(p.M / 4, 4 * 4);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    TO1_CASE(3, 3) TO1_CASE(2, 2) TO1_CASE(4, 4) TO1_CASE(1, 1) TO1_CASE(2, 1) TO1_CASE(1, 2)
+    tg_set_error("smallconv: no to1conv configuration for taps %dx%d", p.TH, p.TW);
+    return TG_ERR_ARG;
+}
+
+// ---- weight gradients ------------------------------------------------------------------------------------
+// Cin == 1: dW[co][tap] = sum_pix dy[pix][co] * x[pix@tap]; lane = co.  Persistent workgroups walk 16x16 output
+// tiles (patch staged in LDS per tile), accumulate K*K taps in registers and reduce across the 4 waves once.
+template <int K>
+__global__ __launch_bounds__(256) void c1wgrad_kernel(const WgradParams p, const C1Geom q, int ntiles, float* __restrict__ partial) {
+    extern __shared__ float sm[];
+    float* patch = sm;                             // [PH*PW]
+    float* red = sm + ((q.PH * q.PW + 3) & ~3);    // [4][K][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.y * 64 + lane;
+    float acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
+    for (int tile0 = blockIdx.x; tile0 < ntiles; tile0 += gridDim.x) {
+        int tile = tile0;
+        const int txi = tile % q.tiles_x;
+        tile /= q.tiles_x;
+        const int tyi = tile % q.tiles_y, b = tile / q.tiles_y;
+        const int oy0 = tyi * C1_T, ox0 = txi * C1_T;
+        __syncthreads();
+        c1_stage_patch(p.x, p.amask, patch, b, oy0 * p.stride - p.pad, ox0 * p.stride - p.pad, q.PH, q.PW, p.H, p.W);
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+            const int ty_o = wave * 4 + r;
+            const int oy = oy0 + ty_o;
+            if (oy >= p.Ho) break;
+#pragma unroll 4
+            for (int tx_o = 0; tx_o < C1_T; ++tx_o) {
+                const int ox = ox0 + tx_o;
+                if (ox >= p.Wo) break;
+                const float dyv = p.dy[(((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + n];
+                const float* pb = patch + ty_o * p.stride * q.PW + tx_o * p.stride;
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx) acc[ky * K + kx] = fmaf(dyv, pb[ky * q.PW + kx], acc[ky * K + kx]);
+            }
+        }
+    }
+    // cross-wave reduction, one kernel row at a time (keeps the LDS footprint small): partial[block][co][tap]
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        __syncthreads();
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) red[(wave * K + kx) * 64 + lane] = acc[ky * K + kx];
+        __syncthreads();
+        for (int i = threadIdx.x; i < K * 64; i += 256) {
+            const int kx = i >> 6, c = i & 63;
+            const float v = red[(0 * K + kx) * 64 + c] + red[(1 * K + kx) * 64 + c] + red[(2 * K + kx) * 64 + c] +
+                            red[(3 * K + kx) * 64 + c];
+            partial[((size_t)blockIdx.x * p.Cout + blockIdx.y * 64 + c) * (K * K) + ky * K + kx] = v;
+        }
+    }
+}
+
+// Cout == 1, C == 64: dW[tap][c] = sum_pix dy[pix] * x[pix@tap][c]; lane = (pixel of a 4-pixel row segment, channel quad)
+template <int K>
+__global__ __launch_bounds__(256) void to1wgrad64_kernel(const WgradParams p, float* __restrict__ partial, int quads_per_block) {
+    __shared__ float red[4][K * K][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = lane >> 4, cq = lane & 15;
+    f32x4 acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int quads = p.Mpix >> 2;
+    const int q_begin = blockIdx.x * quads_per_block;
+    const int q_end = min(quads, q_begin + quads_per_block);
+    for (int q0 = q_begin + wave; q0 < q_end; q0 += 4) {
+        const int q = __builtin_amdgcn_readfirstlane(q0);
+        const int m0 = 4 * q;
+        const int ox0 = m0 % p.Wo;
+        const int t2 = m0 / p.Wo;
+        const int oy = t2 % p.Ho, b = t2 / p.Ho;
+        const int ox = ox0 + e;
+        const float dyv = p.dy[m0 + e];
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = oy * p.stride - p.pad + ky;
+            const bool vy = iy >= 0 && iy < p.H;
+            const size_t rowbase = ((size_t)b * p.H + min(max(iy, 0), p.H - 1)) * p.W;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int ix = ox * p.stride - p.pad + kx;
+                const bool vx = ix >= 0 && ix < p.W;
+                const size_t pix = rowbase + min(max(ix, 0), p.W - 1);
+                float f = (vy && vx) ? dyv : 0.f;
+                if (p.amask) f *= p.amask[pix];
+                const f32x4 x = *reinterpret_cast<const f32x4*>(p.x + pix * 64 + 4 * cq);
+                acc[ky * K + kx] += f * x;
+            }
+        }
+    }
+    // fold the 4 pixel groups (lanes l, l^16, l^32), then the 4 waves through LDS: partial[block][tap][c]
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[t][j];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[t][j] = v;
+        }
+        if (e == 0) *reinterpret_cast<f32x4*>(&red[wave][t][4 * cq]) = acc[t];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K * 64; i += 256) {
+        const int t = i >> 6, c = i & 63;
+        partial[((size_t)blockIdx.x * (K * K) + t) * 64 + c] = red[0][t][c] + red[1][t][c] + red[2][t][c] + red[3][t][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void smallconv_slab_reduce(const float* __restrict__ ws, float* __restrict__ out, size_t n,
+                                                             int splits) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+        double v = 0.0;
+        for (int z = 0; z < splits; ++z) v += (double)ws[(size_t)z * n + idx];
+        out[idx] = (float)v;
+    }
+}
+
+static int to1_wgrad_blocks(const WgradParams& p) {
+    int blocks = cdiv(p.Mpix / 4, 64);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    return blocks;
+}
+static int c1_wgrad_blocks(const WgradParams& p) {
+    int tiles = cdiv(p.Wo, C1_T) * cdiv(p.Ho, C1_T) * p.B;
+    return tiles < 512 ? tiles : 512;
+}
+
+bool smallconv_wgrad_applies(const WgradParams& p) {
+    if (getenv("TG_NO_SMALLCONV")) return false;
+    // Cin == 1 weight gradients measured faster on the MFMA wgrad kernel's scalar-gather path (0.11 vs 0.27 ms for
+    // enc1 at 256^2/B=16); the dedicated kernel stays available behind TG_C1WGRAD=1 for experiments.
+    if (p.C == 1 && p.Cout >= 64 && p.Cout % 64 == 0 && (p.k == 3 || p.k == 4 || p.k == 7) && getenv("TG_C1WGRAD")) return true;
+    if (p.Cout == 1 && p.C == 64 && (p.Wo % 4) == 0 && (p.k == 3 || p.k == 4)) return true;
+    return false;
+}
+size_t smallconv_wgrad_ws_floats(const WgradParams& p) {
+    const int blocks = p.C == 1 ? c1_wgrad_blocks(p) : to1_wgrad_blocks(p);
+    return (size_t)blocks * p.Cout * p.k * p.k * p.C + 64;
+}
+int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream_t s) {
+    int nb;
+    if (p.C == 1) {
+        C1Geom q;
+        q.tiles_x = cdiv(p.Wo, C1_T);
+        q.tiles_y = cdiv(p.Ho, C1_T);
+        q.sy_min = q.sx_min = -p.pad;
+        q.PH = q.PW = (C1_T - 1) * p.stride + p.k;
+        const int ntiles = q.tiles_x * q.tiles_y * p.B;
+        nb = c1_wgrad_blocks(p);
+        dim3 grid(nb, p.Cout / 64);
+        const size_t lds = (((size_t)q.PH * q.PW + 3) / 4 * 4 + (size_t)4 * p.k * 64) * sizeof(float);
+        if (p.k == 7) hipLaunchKernelGGL((c1wgrad_kernel<7>), grid, dim3(256), lds, s, p, q, ntiles, ws);
+        else if (p.k == 4) hipLaunchKernelGGL((c1wgrad_kernel<4>), grid, dim3(256), lds, s, p, q, ntiles, ws);
+        else hipLaunchKernelGGL((c1wgrad_kernel<3>), grid, dim3(256), lds, s, p, q, ntiles, ws);
+        TG_CHECK_LAUNCH("c1wgrad_kernel");
+    } else {
+        const int quads = p.Mpix / 4;
+        const int blocks = to1_wgrad_blocks(p);
+        const int qpb = cdiv(quads, blocks);
+        nb = cdiv(quads, qpb);
+        if (p.k == 4) hipLaunchKernelGGL((to1wgrad64_kernel<4>), dim3(nb), dim3(256), 0, s, p, ws, qpb);
+        else hipLaunchKernelGGL((to1wgrad64_kernel<3>), dim3(nb), dim3(256), 0, s, p, ws, qpb);
+        TG_CHECK_LAUNCH("to1wgrad64_kernel");
+    }
+    const size_t n = (size_t)p.Cout * p.k * p.k * p.C;
+    hipLaunchKernelGGL(smallconv_slab_reduce, dim3(ew_grid((int64_t)n, 256)), dim3(256), 0, s, ws, dw, n, nb);
+    TG_CHECK_LAUNCH("smallconv_slab_reduce");
+    return TG_OK;
+}

@@ -75,7 +75,8 @@ def main():
             lib.tg_prof_enable(0)
             ms0, n0, fl0, by0 = summary(lib, 0)
             ms1, n1, fl1, by1 = summary(lib, 1)
-            ms, fl, by = ms0 + ms1, fl0 + fl1, by0 + by1
+            ms2, n2, fl2, by2 = summary(lib, 2)
+            ms, fl, by = ms0 + ms1 + ms2, fl0 + fl1 + fl2, by0 + by1 + by2
             print(f"{name:8s} {op:6s} {ms / args.reps:8.3f} {fl / ms / 1e9 if ms else 0:7.1f} {by / ms / 1e6 if ms else 0:8.1f}", flush=True)
 
 

@@ -61,6 +61,12 @@ int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask, const flo
 size_t tg_conv_dgrad_ws_bytes(const TgConv* g);
 int tg_conv_dgrad(const TgConv* g, const float* dy, const float* w, const float* in_mask,
                   float* dx, int accumulate, float* ws, size_t ws_bytes, tg_stream_t stream);
+/* Same, with the backward of the activation that PRODUCED x fused into the epilogue:
+ * dx = (convT(dy, w) (.) in_mask) * act'(x_act), x_act = that activation's output [B][H][W][Cin]
+ * (ReLU of the VGG trunk, LeakyReLU of the discriminator's first block). */
+int tg_conv_dgrad_gated(const TgConv* g, const float* dy, const float* w, const float* in_mask,
+                        const float* x_act, int act, float slope, float* dx, float* ws,
+                        size_t ws_bytes, tg_stream_t stream);
 
 /* dw[Cout][k][k][Cin] = sum_pixels dy (x) (x (.) in_mask);  db[Cout] = sum_pixels dy (db may be NULL).
  * Deterministic: split-K partial slabs in ws, reduced in a fixed order. */
@@ -98,10 +104,12 @@ int tg_bn_act_fwd(const float* y, int64_t rows, int C, const float* mean, const 
                   const float* gamma, const float* beta, int act, float slope, float* out,
                   tg_stream_t stream);
 /* Backward of bn_act_fwd in training mode.  dy = dBN(dout (.) act'(.)) [* ratio[row]], dgamma,
- * dbeta.  ratio may be NULL.  dy may alias dout. */
+ * dbeta.  ratio may be NULL.  dy may alias dout.  dbias (may be NULL) receives sum_rows dy, i.e. the
+ * gradient of the bias of the convolution feeding this BatchNorm, obtained in closed form from the
+ * same reduction pass (no extra read of dy). */
 int tg_bn_act_bwd(const float* dout, const float* y, int64_t rows, int C, const float* mean,
                   const float* rstd, const float* gamma, const float* beta, int act, float slope,
-                  const float* ratio, float* dy, float* dgamma, float* dbeta, float* ws,
+                  const float* ratio, float* dy, float* dgamma, float* dbeta, float* dbias, float* ws,
                   size_t ws_bytes, tg_stream_t stream);
 /* din = dout * act'(out) [* ratio[row]] for a conv epilogue activation (out = post-activation).
  * din may alias dout. */
@@ -131,8 +139,9 @@ int tg_sigmoid_composite_bwd(const float* dout, const float* logits, const float
 
 /* ---- VGG trunk helpers (losses.py:31-34,79-90) ------------------------------------------------ */
 int tg_maxpool2_fwd(const float* x, int B, int H, int W, int C, float* out, tg_stream_t stream);
-int tg_maxpool2_bwd(const float* dout, const float* x, int B, int H, int W, int C, float* dx,
-                    tg_stream_t stream);
+/* relu_gate != 0: x is a ReLU output and its backward is fused (no gradient where the max is 0). */
+int tg_maxpool2_bwd(const float* dout, const float* x, int B, int H, int W, int C, int relu_gate,
+                    float* dx, tg_stream_t stream);
 
 /* ---- losses ------------------------------------------------------------------------------------ */
 

@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
                         float v = acc[i][j][r];
                         if (p.bias) v += p.bias[n];
                         v = apply_act(v * rs, p.act, p.slope);
+                        if (p.gate) v *= gate_factor(p, pix * p.N + n);
                         float* d = p.dst + pix * p.N + n;
                         if (p.accumulate) v += *d;
                         *d = v;
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IGemmParams p
         if (p.bias) v += p.bias[n];
         if (p.rowscale) v *= p.rowscale[pix];
         v = apply_act(v, p.act, p.slope);
+        if (p.gate) v *= gate_factor(p, pix * p.N + n);
         float* d = p.dst + pix * p.N + n;
         if (p.accumulate) v += *d;
         *d = v;
@@ -613,6 +615,7 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
                         float v = acc[i][j][r];
                         if (p.bias) v += p.bias[n];
                         v = apply_act(v * rs, p.act, p.slope);
+                        if (p.gate) v *= gate_factor(p, pix * p.N + n);
                         float* d = p.dst + pix * p.N + n;
                         if (p.accumulate) v += *d;
                         *d = v;
@@ -806,8 +809,19 @@ extern "C" size_t tg_conv_dgrad_ws_bytes(const TgConv* g) {
     return (wt + (want < cap ? want : cap)) * sizeof(float);
 }
 
+static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, const float* in_mask, float* dx, int accumulate,
+                           const float* gate, int gate_act, float gate_slope, float* ws, size_t ws_bytes, tg_stream_t stream);
 extern "C" int tg_conv_dgrad(const TgConv* g, const float* dy, const float* w, const float* in_mask, float* dx,
                              int accumulate, float* ws, size_t ws_bytes, tg_stream_t stream) {
+    return conv_dgrad_impl(g, dy, w, in_mask, dx, accumulate, nullptr, 0, 0.f, ws, ws_bytes, stream);
+}
+extern "C" int tg_conv_dgrad_gated(const TgConv* g, const float* dy, const float* w, const float* in_mask, const float* x_act,
+                                   int act, float slope, float* dx, float* ws, size_t ws_bytes, tg_stream_t stream) {
+    TG_REQUIRE(x_act != nullptr && (act == TG_ACT_RELU || act == TG_ACT_LEAKY), "tg_conv_dgrad_gated: needs x_act and a ReLU/LeakyReLU");
+    return conv_dgrad_impl(g, dy, w, in_mask, dx, 0, x_act, act, slope, ws, ws_bytes, stream);
+}
+static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, const float* in_mask, float* dx, int accumulate,
+                           const float* gate, int gate_act, float gate_slope, float* ws, size_t ws_bytes, tg_stream_t stream) {
     int rc = check_conv(g, "tg_conv_dgrad");
     if (rc) return rc;
     TG_REQUIRE(dy && w && dx && ws, "tg_conv_dgrad: null pointer");
@@ -841,6 +855,7 @@ extern "C" int tg_conv_dgrad(const TgConv* g, const float* dy, const float* w, c
             p.KW = g->k; p.kstep = st;
             p.Kfull = taps * g->Cout;
             p.act = TG_ACT_NONE; p.slope = 0.f; p.accumulate = accumulate;
+            p.gate = gate; p.gate_act = gate_act; p.gate_slope = gate_slope;
             p.Ktot = p.TH * p.TW * p.C; p.nchunks = cdiv(p.C, 32);
             p.T = (p.C % 4) ? cdiv(p.Ktot, 32) : p.TH * p.TW * p.nchunks;
             plan_splits(p, ws2_floats);

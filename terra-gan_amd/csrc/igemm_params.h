@@ -21,7 +21,14 @@ struct IGemmParams {
     int act;
     float slope;
     int accumulate;
+    const float* gate;      // optional [dst pixels][N]: result *= act'(gate) (fused activation backward)
+    int gate_act;
+    float gate_slope;
 };
+__device__ __forceinline__ float gate_factor(const IGemmParams& p, size_t idx) {
+    const float gv = p.gate[idx];
+    return gv > 0.f ? 1.f : (p.gate_act == TG_ACT_LEAKY ? p.gate_slope : 0.f);
+}
 
 struct WgradParams {
     const float* x;

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 extern "C" size_t tg_bn_ws_bytes(int64_t rows, int C) {
     if (rows <= 0 || C <= 0) return 0;
     ColGeom g = col_geom(rows, C);
-    return align_up((size_t)g.grid * 2 * C, 64) * sizeof(float);
+    return align_up((size_t)g.grid * 5 * C, 64) * sizeof(float);
 }
 extern "C" int tg_bn_stats(const float* y, int64_t rows, int C, float eps, float momentum, float* save_mean,
                            float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
@@ -339,20 +339,29 @@ struct BnBwdF {
     const float* beta;
     int C, act;
     float slope;
-    __device__ void operator()(int64_t r, int c, float (&q)[2]) const {
+    const float* ratio;   // optional per-row scale of the conv output (partial conv)
+    __device__ void operator()(int64_t r, int c, float (&q)[5]) const {
         float xh = (y[r * C + c] - mean[c]) * rstd[c];
         float g = dout[r * C + c] * act_grad(xh * gamma[c] + beta[c], act, slope);
+        float rr = ratio ? ratio[r] : 1.f;
         q[0] += g;
         q[1] += g * xh;
+        q[2] += rr * g;      // the three extra sums give the conv-bias gradient sum_rows ratio*dy in closed form
+        q[3] += rr * xh;
+        q[4] += rr;
     }
 };
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ partial, int nblocks, int C,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    double q[2];
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ partial, int nblocks, int C, double n,
+                                                           const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ dbias) {
+    double q[5];
     int c;
-    if (!final_reduce<2>(partial, nblocks, C, q, &c)) return;
+    if (!final_reduce<5>(partial, nblocks, C, q, &c)) return;
     dbeta[c] = (float)q[0];
     dgamma[c] = (float)q[1];
+    // dy = gamma*rstd*(g - dbeta/n - xhat*dgamma/n)  =>  sum_rows ratio*dy
+    if (dbias) dbias[c] = (float)((double)gamma[c] * (double)rstd[c] * (q[2] - q[0] / n * q[4] - q[1] / n * q[3]));
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                            int64_t rows, int C, const float* __restrict__ mean,
@@ -374,16 +383,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 extern "C" int tg_bn_act_bwd(const float* dout, const float* y, int64_t rows, int C, const float* mean, const float* rstd,
                              const float* gamma, const float* beta, int act, float slope, const float* ratio, float* dy,
-                             float* dgamma, float* dbeta, float* ws, size_t ws_bytes, tg_stream_t stream) {
+                             float* dgamma, float* dbeta, float* dbias, float* ws, size_t ws_bytes, tg_stream_t stream) {
     TG_REQUIRE(dout && y && mean && rstd && gamma && beta && dy && dgamma && dbeta && ws, "tg_bn_act_bwd: null pointer");
     TG_REQUIRE(C >= 1 && C <= 1024 && rows > 0, "tg_bn_act_bwd: bad dims");
     TG_REQUIRE(ws_bytes >= tg_bn_ws_bytes(rows, C), "tg_bn_act_bwd: workspace too small");
     ColGeom g = col_geom(rows, C);
-    BnBwdF f{dout, y, mean, rstd, gamma, beta, C, act, slope};
-    hipLaunchKernelGGL((colreduce_kernel<2, BnBwdF>), dim3(g.grid), dim3(256), 0, S(stream), f, rows, C, g.cpp, g.rlanes,
+    BnBwdF f{dout, y, mean, rstd, gamma, beta, C, act, slope, ratio};
+    hipLaunchKernelGGL((colreduce_kernel<5, BnBwdF>), dim3(g.grid), dim3(256), 0, S(stream), f, rows, C, g.cpp, g.rlanes,
                        g.rows_per_block, ws);
     TG_CHECK_LAUNCH("bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fr_grid(C)), dim3(256), 0, S(stream), ws, g.grid, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fr_grid(C)), dim3(256), 0, S(stream), ws, g.grid, C, (double)rows, gamma, rstd,
+                       dgamma, dbeta, dbias);
     TG_CHECK_LAUNCH("bn_bwd_final");
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * C, 256)), dim3(256), 0, S(stream), dout, y, rows, C, mean,
                        rstd, gamma, beta, act, slope, ratio, dgamma, dbeta, dy);
@@ -621,7 +631,7 @@ extern "C" int tg_maxpool2_fwd(const float* x, int B, int H, int W, int C, float
 }
 // gradient goes to the first maximum in window scan order (ATen CPU max_pool2d)
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x, int B,
-                                                           int H, int W, int C, float* __restrict__ dx) {
+                                                           int H, int W, int C, int relu_gate, float* __restrict__ dx) {
     const int Ho = H / 2, Wo = W / 2;
     const int64_t total = (int64_t)B * H * W * C;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -642,15 +652,16 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
             for (int e = 1; e < 4; ++e)
                 if (v[e] > best) { best = v[e]; am = e; }
             const int me = (iy & 1) * 2 + (ix & 1);
-            if (me == am) g = dout[(((int64_t)b * Ho + oy) * Wo + ox) * C + c];
+            if (me == am && !(relu_gate && best <= 0.f)) g = dout[(((int64_t)b * Ho + oy) * Wo + ox) * C + c];
         }
         dx[idx] = g;
     }
 }
-extern "C" int tg_maxpool2_bwd(const float* dout, const float* x, int B, int H, int W, int C, float* dx, tg_stream_t stream) {
+extern "C" int tg_maxpool2_bwd(const float* dout, const float* x, int B, int H, int W, int C, int relu_gate, float* dx,
+                               tg_stream_t stream) {
     TG_REQUIRE(dout && x && dx && B > 0 && H > 1 && W > 1 && C > 0, "tg_maxpool2_bwd: bad arguments");
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid((int64_t)B * H * W * C, 256)), dim3(256), 0, S(stream), dout, x, B, H, W,
-                       C, dx);
+                       C, relu_gate, dx);
     TG_CHECK_LAUNCH("maxpool2_bwd_kernel");
     return TG_OK;
 }

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void c1conv_kernel(const IGemmParams p, const 
             float v = acc + bias;
             if (p.rowscale) v *= p.rowscale[opix];
             v = apply_act(v, p.act, p.slope);
+            if (p.gate) v *= gate_factor(p, opix * p.N + n);
             float* d = p.dst + opix * p.N + n;
             if (p.accumulate) v += *d;
             *d = v;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void to1conv64_kernel(const IGemmParams p) {
             float r = acc + bias;
             if (p.rowscale) r *= p.rowscale[opix];
             r = apply_act(r, p.act, p.slope);
+            if (p.gate) r *= gate_factor(p, opix);
             if (p.accumulate) r += p.dst[opix];
             p.dst[opix] = r;
         }

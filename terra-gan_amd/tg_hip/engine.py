@@ -48,10 +48,10 @@ def _pconv_fwd(P, name, k, s, p, x, in_mask, ratio, training, premasked=False):
 def _pconv_bwd(P, c, da, grads, dx_out=None, want_dx=True):
     """da: grad w.r.t. the layer's ReLU output (consumed in place).  Returns dx (or None)."""
     name = c.name
-    dyr, dgamma, dbeta = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU,
-                                      ratio=c.ratio)
-    dw, db = O.conv_wgrad(c.x, dyr, P[f"{name}.input_conv.weight"], c.k, c.s, c.p,
-                          in_mask=None if getattr(c, "premasked", False) else c.in_mask)
+    dyr, dgamma, dbeta, db = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU,
+                                          ratio=c.ratio)
+    dw, _ = O.conv_wgrad(c.x, dyr, P[f"{name}.input_conv.weight"], c.k, c.s, c.p,
+                         in_mask=None if getattr(c, "premasked", False) else c.in_mask, want_bias=False)
     grads[f"{name}.input_conv.weight"], grads[f"{name}.input_conv.bias"] = dw, db
     grads[f"{name}.bn.weight"], grads[f"{name}.bn.bias"] = dgamma, dbeta
     if not want_dx:
@@ -157,21 +157,30 @@ def discriminator_forward(P, img, training=True):
 def discriminator_backward(P, ctx, dlogits, want_wgrad=True, want_dimg=False):
     """Returns (grads dict, dimg [B][H][W][C] or None).  want_wgrad=False skips the parameter
     gradients the reference computes and then discards in the generator step (train.py:204,210)."""
-    grads, da = {}, dlogits
+    grads, da, gated = {}, dlogits, False
     for li in range(len(ctx.layers) - 1, -1, -1):
         c = ctx.layers[li]
         w = P[f"model.{c.ci}.weight"]
+        db = None
         if c.bi is None:
-            dy = O.act_bwd(da, c.a, c.act, 0.2) if c.act != O.ACT_NONE else da
+            # the activation backward of a BN-less block is fused into the dgrad epilogue of the layer above it
+            dy = da if (gated or c.act == O.ACT_NONE) else O.act_bwd(da, c.a, c.act, 0.2)
         else:
-            dy, dgamma, dbeta = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"model.{c.bi}.weight"], P[f"model.{c.bi}.bias"],
-                                             O.ACT_LEAKY, 0.2)
+            dy, dgamma, dbeta, db = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"model.{c.bi}.weight"], P[f"model.{c.bi}.bias"],
+                                                 O.ACT_LEAKY, 0.2, want_dbias=want_wgrad)
             if want_wgrad:
                 grads[f"model.{c.bi}.weight"], grads[f"model.{c.bi}.bias"] = dgamma, dbeta
         if want_wgrad:
-            grads[f"model.{c.ci}.weight"], grads[f"model.{c.ci}.bias"] = O.conv_wgrad(c.x, dy, w, c.k, c.s, c.p)
+            dw, db2 = O.conv_wgrad(c.x, dy, w, c.k, c.s, c.p, want_bias=db is None)
+            grads[f"model.{c.ci}.weight"], grads[f"model.{c.ci}.bias"] = dw, (db if db is not None else db2)
+        gated = False
         if li > 0 or want_dimg:
-            da = O.conv_dgrad(dy, w, tuple(c.x.shape), c.k, c.s, c.p)
+            below = ctx.layers[li - 1] if li > 0 else None
+            if below is not None and below.bi is None and below.act != O.ACT_NONE:
+                da = O.conv_dgrad(dy, w, tuple(c.x.shape), c.k, c.s, c.p, gate=below.a, gate_act=below.act, gate_slope=0.2)
+                gated = True
+            else:
+                da = O.conv_dgrad(dy, w, tuple(c.x.shape), c.k, c.s, c.p)
         else:
             da = None
     return grads, da
@@ -210,14 +219,25 @@ def vgg_forward(V, img, keep=True):
 
 def vgg_backward(ctx, dfeat, nb=None):
     """Input gradient only (weights are frozen, losses.py:33-34) for the first `nb` samples."""
-    da = dfeat
-    for st in reversed(ctx.steps):
+    da, gated = dfeat, False
+    steps = ctx.steps
+    for i in range(len(steps) - 1, -1, -1):
+        st = steps[i]
         if st.kind == "M":
+            # the pooled tensor is a ReLU output: its backward is fused into the pool backward
             x = st.x if nb is None else st.x[:nb]
-            da = O.maxpool2_bwd(da, x)
+            da = O.maxpool2_bwd(da, x, relu_gate=True)
+            gated = True
         else:
             a = st.a if nb is None else st.a[:nb]
-            dy = O.act_bwd(da, a, O.ACT_RELU)
+            dy = da if gated else O.act_bwd(da, a, O.ACT_RELU)
             shp = st.x_shape if nb is None else (nb,) + tuple(st.x_shape[1:])
-            da = O.conv_dgrad(dy, st.w, shp, 3, 1, 1)
+            below = steps[i - 1] if i > 0 else None
+            if below is not None and below.kind == "C":      # input of this conv = ReLU output of the conv below
+                ga = below.a if nb is None else below.a[:nb]
+                da = O.conv_dgrad(dy, st.w, shp, 3, 1, 1, gate=ga, gate_act=O.ACT_RELU)
+                gated = True
+            else:
+                da = O.conv_dgrad(dy, st.w, shp, 3, 1, 1)
+                gated = False
     return da.reshape(da.shape[0], da.shape[1], da.shape[2])

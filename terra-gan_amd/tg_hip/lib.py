@@ -30,6 +30,7 @@ SIGNATURES = {
     "tg_conv_fwd": (I, [CP, P, P, P, P, P, I, F, P, P, SZ, P]),
     "tg_conv_dgrad_ws_bytes": (SZ, [CP]),
     "tg_conv_dgrad": (I, [CP, P, P, P, P, I, P, SZ, P]),
+    "tg_conv_dgrad_gated": (I, [CP, P, P, P, P, I, F, P, P, SZ, P]),
     "tg_conv_wgrad_ws_bytes": (SZ, [CP]),
     "tg_conv_wgrad": (I, [CP, P, P, P, P, P, P, SZ, P]),
     "tg_fold_cin": (I, [P, I, I, I, P, P]),
@@ -39,14 +40,14 @@ SIGNATURES = {
     "tg_bn_stats": (I, [P, I64, I, F, F, P, P, P, P, P, P, SZ, P]),
     "tg_bn_eval_stats": (I, [P, P, I, F, P, P, P]),
     "tg_bn_act_fwd": (I, [P, I64, I, P, P, P, P, I, F, P, P]),
-    "tg_bn_act_bwd": (I, [P, P, I64, I, P, P, P, P, I, F, P, P, P, P, P, SZ, P]),
+    "tg_bn_act_bwd": (I, [P, P, I64, I, P, P, P, P, I, F, P, P, P, P, P, P, SZ, P]),
     "tg_act_bwd": (I, [P, P, I64, I, I, F, P, P, P]),
     "tg_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P]),
     "tg_upcat_bwd": (I, [P, I, I, I, I, I, I, I, P, P, P]),
     "tg_sigmoid_composite_fwd": (I, [P, P, P, I64, P, P]),
     "tg_sigmoid_composite_bwd": (I, [P, P, P, I64, P, P, P]),
     "tg_maxpool2_fwd": (I, [P, I, I, I, I, P, P]),
-    "tg_maxpool2_bwd": (I, [P, P, I, I, I, I, P, P]),
+    "tg_maxpool2_bwd": (I, [P, P, I, I, I, I, I, P, P]),
     "tg_pixel_loss_ws_bytes": (SZ, [I, I, I]),
     "tg_pixel_losses": (I, [P, P, P, P, I, I, I, F, F, F, F, P, P, P, I, P, SZ, P]),
     "tg_reduce_ws_bytes": (SZ, [I64]),

@@ -87,9 +87,10 @@ def conv_fwd(x, w, bias, k, stride, pad, in_mask=None, ratio=None, act=ACT_NONE,
     return y
 
 
-def conv_dgrad(dy, w, x_shape, k, stride, pad, in_mask=None, out=None):
-    """dx for an input of shape x_shape=[B,H,W,Cin]; accumulates into `out` when given."""
-    _chk(dy, "dy"); _chk(in_mask, "in_mask"); _chk(out, "out")
+def conv_dgrad(dy, w, x_shape, k, stride, pad, in_mask=None, out=None, gate=None, gate_act=ACT_RELU, gate_slope=0.0):
+    """dx for an input of shape x_shape=[B,H,W,Cin]; accumulates into `out` when given.  `gate` = output of the
+    activation that produced x: its backward is fused into the epilogue (dx *= act'(gate))."""
+    _chk(dy, "dy"); _chk(in_mask, "in_mask"); _chk(out, "out"); _chk(gate, "gate")
     wv = weight_view(w)
     B, H, W, Cin = x_shape
     g = L.TgConv(B, H, W, Cin, dy.shape[1], dy.shape[2], dy.shape[3], k, stride, pad)
@@ -97,6 +98,11 @@ def conv_dgrad(dy, w, x_shape, k, stride, pad, in_mask=None, out=None):
     dx = out if out is not None else empty(B, H, W, Cin, like=dy)
     lib = _lib()
     ws = workspace(lib.tg_conv_dgrad_ws_bytes(C.byref(g)))
+    if gate is not None:
+        assert out is None and tuple(gate.shape) == tuple(x_shape)
+        L.check(lib.tg_conv_dgrad_gated(C.byref(g), _p(dy), _p(wv), _p(in_mask), _p(gate), gate_act, gate_slope, _p(dx), _p(ws),
+                                        ws.numel() * 4, _stream()), "tg_conv_dgrad_gated")
+        return dx
     L.check(lib.tg_conv_dgrad(C.byref(g), _p(dy), _p(wv), _p(in_mask), _p(dx), acc, _p(ws), ws.numel() * 4, _stream()),
             "tg_conv_dgrad")
     return dx
@@ -179,18 +185,21 @@ def bn_act_fwd(y, mean, rstd, gamma, beta, act, slope=0.0):
     return out
 
 
-def bn_act_bwd(dout, y, mean, rstd, gamma, beta, act, slope=0.0, ratio=None, inplace=True):
-    """Returns (dy, dgamma, dbeta); dy overwrites dout when inplace."""
+def bn_act_bwd(dout, y, mean, rstd, gamma, beta, act, slope=0.0, ratio=None, inplace=True, want_dbias=True):
+    """Returns (dy, dgamma, dbeta, dbias); dy overwrites dout when inplace.  dbias = sum_rows dy (the gradient of
+    the bias of the conv feeding this BatchNorm), from the same reduction pass."""
     _chk(dout, "dout"); _chk(y, "y"); _chk(ratio, "ratio")
     Cc = y.shape[-1]
     rows = y.numel() // Cc
     dy = dout if inplace else torch.empty_like(dout)
     dgamma, dbeta = empty(Cc, like=y), empty(Cc, like=y)
+    dbias = empty(Cc, like=y) if want_dbias else None
     lib = _lib()
     ws = workspace(lib.tg_bn_ws_bytes(rows, Cc))
     L.check(lib.tg_bn_act_bwd(_p(dout), _p(y), rows, Cc, _p(mean), _p(rstd), _p(gamma.detach()), _p(beta.detach()), act, slope,
-                              _p(ratio), _p(dy), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 4, _stream()), "tg_bn_act_bwd")
-    return dy, dgamma, dbeta
+                              _p(ratio), _p(dy), _p(dgamma), _p(dbeta), _p(dbias), _p(ws), ws.numel() * 4, _stream()),
+            "tg_bn_act_bwd")
+    return dy, dgamma, dbeta, dbias
 
 
 def act_bwd(dout, out, act, slope=0.0, ratio=None, inplace=True):
@@ -242,10 +251,10 @@ def maxpool2_fwd(x):
     return out
 
 
-def maxpool2_bwd(dout, x):
+def maxpool2_bwd(dout, x, relu_gate=False):
     B, H, W, Cc = x.shape
     dx = torch.empty_like(x)
-    L.check(_lib().tg_maxpool2_bwd(_p(dout), _p(x), B, H, W, Cc, _p(dx), _stream()), "tg_maxpool2_bwd")
+    L.check(_lib().tg_maxpool2_bwd(_p(dout), _p(x), B, H, W, Cc, 1 if relu_gate else 0, _p(dx), _stream()), "tg_maxpool2_bwd")
     return dx
 
 

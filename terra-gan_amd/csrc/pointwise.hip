@@ -87,6 +87,62 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, int64_t rows, int C
 }
 
 
+// Vectorised first stage for C % 4 == 0: a thread owns 4 consecutive channels (one 16-byte load per operand and
+// row), the block covers `qpp` channel quads x `rlanes` rows per pass.  Functors implement
+//   void quad(int64_t row, int c0, float (&q)[NQ][4])   // accumulate channels c0..c0+3 of one row
+template <int NQ, class F>
+__global__ __launch_bounds__(256) void colreduce4_kernel(F f, int64_t rows, int C, int qpp, int rlanes, int64_t rows_per_block,
+                                                         float* __restrict__ partial) {
+    __shared__ float red[NQ][4][256];
+    const int tid = threadIdx.x;
+    const int cq = tid % qpp, rl = tid / qpp;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    const int nquads = C >> 2;
+    for (int q0 = 0; q0 < nquads; q0 += qpp) {       // column passes (C > 1024 never happens: one pass for C <= 1024)
+        const int c0 = (q0 + cq) * 4;
+        float q[NQ][4];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[i][e] = 0.f;
+        if (rl < rlanes && c0 < C)
+            for (int64_t r = r0 + rl; r < r1; r += rlanes) f.quad(r, c0, q);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[i][e][tid] = (rl < rlanes && c0 < C) ? q[i][e] : 0.f;
+        __syncthreads();
+        if (rl == 0 && c0 < C) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float sacc = 0.f;
+                    for (int l = 0; l < rlanes; ++l) sacc += red[i][e][l * qpp + cq];
+                    partial[((size_t)blockIdx.x * NQ + i) * C + c0 + e] = sacc;
+                }
+        }
+    }
+}
+struct ColGeom4 {
+    int qpp, rlanes, grid;
+    int64_t rows_per_block;
+};
+static ColGeom4 col_geom4(int64_t rows, int C) {
+    ColGeom4 g;
+    const int nquads = C / 4;
+    g.qpp = nquads < 256 ? nquads : 256;
+    g.rlanes = 256 / g.qpp;
+    int64_t want = cdiv64(rows, (int64_t)g.rlanes * 8);
+    if (want > 512) want = 512;
+    if (want < 1) want = 1;
+    g.rows_per_block = cdiv64(rows, want);
+    g.grid = (int)cdiv64(rows, g.rows_per_block);
+    return g;
+}
+
 // Second stage shared by every column reduction: 16 columns x 16 partial-row lanes per 256-thread block;
 // lane rl sums partial rows rl, rl+16, ... in fp64 (fixed order), the 16 lanes are combined through LDS in
 // a fixed order as well -> deterministic.  Returns true in the thread that owns column *c_out (rl == 0).
@@ -224,6 +280,16 @@ struct BnStatF {
         q[0] += d;
         q[1] += d * d;
     }
+    __device__ void quad(int64_t r, int c0, float (&q)[2][4]) const {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * C + c0);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(y + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float d = v[e] - sh[e];
+            q[0][e] += d;
+            q[1][e] += d * d;
+        }
+    }
 };
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
                                                           const float* __restrict__ y, int64_t rows, float eps,
@@ -247,7 +313,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 extern "C" size_t tg_bn_ws_bytes(int64_t rows, int C) {
     if (rows <= 0 || C <= 0) return 0;
     ColGeom g = col_geom(rows, C);
-    return align_up((size_t)g.grid * 5 * C, 64) * sizeof(float);
+    int grid = g.grid;
+    if (C % 4 == 0) {
+        ColGeom4 g4 = col_geom4(rows, C);
+        if (g4.grid > grid) grid = g4.grid;
+    }
+    return align_up((size_t)grid * 5 * C, 64) * sizeof(float);
 }
 extern "C" int tg_bn_stats(const float* y, int64_t rows, int C, float eps, float momentum, float* save_mean,
                            float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
@@ -256,12 +327,21 @@ extern "C" int tg_bn_stats(const float* y, int64_t rows, int C, float eps, float
     TG_REQUIRE(C >= 1 && C <= 1024, "tg_bn_stats: C=%d out of range [1,1024]", C);
     TG_REQUIRE(rows > 1, "tg_bn_stats: Expected more than 1 value per channel when training (rows=%lld)", (long long)rows);
     TG_REQUIRE(ws_bytes >= tg_bn_ws_bytes(rows, C), "tg_bn_stats: workspace too small");
-    ColGeom g = col_geom(rows, C);
     BnStatF f{y, C};
-    hipLaunchKernelGGL((colreduce_kernel<2, BnStatF>), dim3(g.grid), dim3(256), 0, S(stream), f, rows, C, g.cpp, g.rlanes,
-                       g.rows_per_block, ws);
+    int nblocks;
+    if (C % 4 == 0) {
+        ColGeom4 g = col_geom4(rows, C);
+        nblocks = g.grid;
+        hipLaunchKernelGGL((colreduce4_kernel<2, BnStatF>), dim3(g.grid), dim3(256), 0, S(stream), f, rows, C, g.qpp, g.rlanes,
+                           g.rows_per_block, ws);
+    } else {
+        ColGeom g = col_geom(rows, C);
+        nblocks = g.grid;
+        hipLaunchKernelGGL((colreduce_kernel<2, BnStatF>), dim3(g.grid), dim3(256), 0, S(stream), f, rows, C, g.cpp, g.rlanes,
+                           g.rows_per_block, ws);
+    }
     TG_CHECK_LAUNCH("bn_stats");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(fr_grid(C)), dim3(256), 0, S(stream), ws, g.grid, C, y, rows, eps,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(fr_grid(C)), dim3(256), 0, S(stream), ws, nblocks, C, y, rows, eps,
                        momentum, save_mean, save_rstd, running_mean, running_var, num_batches_tracked);
     TG_CHECK_LAUNCH("bn_finalize");
     return TG_OK;
@@ -350,6 +430,23 @@ struct BnBwdF {
         q[3] += rr * xh;
         q[4] += rr;
     }
+    __device__ void quad(int64_t r, int c0, float (&q)[5][4]) const {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * C + c0);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dout + r * C + c0);
+        const f32x4 mv = *reinterpret_cast<const f32x4*>(mean + c0), rv = *reinterpret_cast<const f32x4*>(rstd + c0);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + c0), bv = *reinterpret_cast<const f32x4*>(beta + c0);
+        const float rr = ratio ? ratio[r] : 1.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float xh = (yv[e] - mv[e]) * rv[e];
+            float g = dv[e] * act_grad(xh * gv[e] + bv[e], act, slope);
+            q[0][e] += g;
+            q[1][e] += g * xh;
+            q[2][e] += rr * g;
+            q[3][e] += rr * xh;
+            q[4][e] += rr;
+        }
+    }
 };
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ partial, int nblocks, int C, double n,
                                                            const float* __restrict__ gamma, const float* __restrict__ rstd,
@@ -371,6 +468,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ dbeta, float* __restrict__ dy) {
     const int64_t total = rows * C;
     const float inv_n = 1.0f / (float)rows;
+    if ((C & 3) == 0) {
+        const int64_t n4 = total >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            const int c = (int)((i * 4) % C);
+            const int64_t r = (i * 4) / C;
+            const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i], dv = reinterpret_cast<const f32x4*>(dout)[i];
+            const float rr = ratio ? ratio[r] : 1.f;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float xh = (yv[e] - mean[c + e]) * rstd[c + e];
+                float g = dv[e] * act_grad(xh * gamma[c + e] + beta[c + e], act, slope);
+                o[e] = gamma[c + e] * rstd[c + e] * (g - dbeta[c + e] * inv_n - xh * dgamma[c + e] * inv_n) * rr;
+            }
+            reinterpret_cast<f32x4*>(dy)[i] = o;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const int64_t r = i / C;
@@ -387,15 +502,24 @@ extern "C" int tg_bn_act_bwd(const float* dout, const float* y, int64_t rows, in
     TG_REQUIRE(dout && y && mean && rstd && gamma && beta && dy && dgamma && dbeta && ws, "tg_bn_act_bwd: null pointer");
     TG_REQUIRE(C >= 1 && C <= 1024 && rows > 0, "tg_bn_act_bwd: bad dims");
     TG_REQUIRE(ws_bytes >= tg_bn_ws_bytes(rows, C), "tg_bn_act_bwd: workspace too small");
-    ColGeom g = col_geom(rows, C);
     BnBwdF f{dout, y, mean, rstd, gamma, beta, C, act, slope, ratio};
-    hipLaunchKernelGGL((colreduce_kernel<5, BnBwdF>), dim3(g.grid), dim3(256), 0, S(stream), f, rows, C, g.cpp, g.rlanes,
-                       g.rows_per_block, ws);
+    int nblocks;
+    if (C % 4 == 0) {
+        ColGeom4 g = col_geom4(rows, C);
+        nblocks = g.grid;
+        hipLaunchKernelGGL((colreduce4_kernel<5, BnBwdF>), dim3(g.grid), dim3(256), 0, S(stream), f, rows, C, g.qpp, g.rlanes,
+                           g.rows_per_block, ws);
+    } else {
+        ColGeom g = col_geom(rows, C);
+        nblocks = g.grid;
+        hipLaunchKernelGGL((colreduce_kernel<5, BnBwdF>), dim3(g.grid), dim3(256), 0, S(stream), f, rows, C, g.cpp, g.rlanes,
+                           g.rows_per_block, ws);
+    }
     TG_CHECK_LAUNCH("bn_bwd_reduce");
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fr_grid(C)), dim3(256), 0, S(stream), ws, g.grid, C, (double)rows, gamma, rstd,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fr_grid(C)), dim3(256), 0, S(stream), ws, nblocks, C, (double)rows, gamma, rstd,
                        dgamma, dbeta, dbias);
     TG_CHECK_LAUNCH("bn_bwd_final");
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * C, 256)), dim3(256), 0, S(stream), dout, y, rows, C, mean,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((C % 4) ? rows * C : rows * C / 4, 256)), dim3(256), 0, S(stream), dout, y, rows, C, mean,
                        rstd, gamma, beta, act, slope, ratio, dgamma, dbeta, dy);
     TG_CHECK_LAUNCH("bn_bwd_apply");
     return TG_OK;
@@ -603,65 +727,88 @@ extern "C" int tg_sigmoid_composite_bwd(const float* dout, const float* logits, 
 // =================================================================================================
 // 2x2 max-pool (VGG trunk)
 // =================================================================================================
+template <int V>
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C,
                                                            float* __restrict__ out) {
     const int Ho = H / 2, Wo = W / 2;
-    const int64_t total = (int64_t)B * Ho * Wo * C;
+    const int cv = C / V;
+    const int64_t total = (int64_t)B * Ho * Wo * cv;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int c = (int)(idx % C);
-        int64_t t = idx / C;
+        const int c = (int)(idx % cv) * V;
+        int64_t t = idx / cv;
         const int ox = (int)(t % Wo);
         t /= Wo;
         const int oy = (int)(t % Ho);
         const int b = (int)(t / Ho);
         const float* p0 = x + (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
-        float v = p0[0];
-        v = fmaxf(v, p0[C]);
-        v = fmaxf(v, p0[(int64_t)W * C]);
-        v = fmaxf(v, p0[(int64_t)W * C + C]);
-        out[idx] = v;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float v = p0[e];
+            v = fmaxf(v, p0[C + e]);
+            v = fmaxf(v, p0[(int64_t)W * C + e]);
+            v = fmaxf(v, p0[(int64_t)W * C + C + e]);
+            out[(((int64_t)b * Ho + oy) * Wo + ox) * C + c + e] = v;
+        }
     }
 }
 extern "C" int tg_maxpool2_fwd(const float* x, int B, int H, int W, int C, float* out, tg_stream_t stream) {
     TG_REQUIRE(x && out && B > 0 && H > 1 && W > 1 && C > 0, "tg_maxpool2_fwd: bad arguments");
-    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_grid((int64_t)B * (H / 2) * (W / 2) * C, 256)), dim3(256), 0, S(stream), x,
-                       B, H, W, C, out);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((maxpool2_fwd_kernel<4>), dim3(ew_grid((int64_t)B * (H / 2) * (W / 2) * C / 4, 256)), dim3(256), 0,
+                           S(stream), x, B, H, W, C, out);
+    else
+        hipLaunchKernelGGL((maxpool2_fwd_kernel<1>), dim3(ew_grid((int64_t)B * (H / 2) * (W / 2) * C, 256)), dim3(256), 0, S(stream),
+                           x, B, H, W, C, out);
     TG_CHECK_LAUNCH("maxpool2_fwd_kernel");
     return TG_OK;
 }
-// gradient goes to the first maximum in window scan order (ATen CPU max_pool2d)
+// gradient goes to the first maximum in window scan order (ATen CPU max_pool2d); one thread per pooling window and
+// V channels writes the window's four input gradients (odd trailing row/column, which no window covers, get zero)
+template <int V>
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x, int B,
                                                            int H, int W, int C, int relu_gate, float* __restrict__ dx) {
-    const int Ho = H / 2, Wo = W / 2;
-    const int64_t total = (int64_t)B * H * W * C;
+    const int Hc = (H + 1) / 2, Wc = (W + 1) / 2, Ho = H / 2, Wo = W / 2;
+    const int cv = C / V;
+    const int64_t total = (int64_t)B * Hc * Wc * cv;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int c = (int)(idx % C);
-        int64_t t = idx / C;
-        const int ix = (int)(t % W);
-        t /= W;
-        const int iy = (int)(t % H);
-        const int b = (int)(t / H);
-        const int oy = iy >> 1, ox = ix >> 1;
-        float g = 0.f;
-        if (oy < Ho && ox < Wo) {
-            const float* p0 = x + (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
-            const float v[4] = {p0[0], p0[C], p0[(int64_t)W * C], p0[(int64_t)W * C + C]};
-            int am = 0;
-            float best = v[0];
+        const int c = (int)(idx % cv) * V;
+        int64_t t = idx / cv;
+        const int ox = (int)(t % Wc);
+        t /= Wc;
+        const int oy = (int)(t % Hc);
+        const int b = (int)(t / Hc);
+        const int64_t base = (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+        const bool full = oy < Ho && ox < Wo;
+        const bool has_r = 2 * ox + 1 < W, has_d = 2 * oy + 1 < H;
 #pragma unroll
-            for (int e = 1; e < 4; ++e)
-                if (v[e] > best) { best = v[e]; am = e; }
-            const int me = (iy & 1) * 2 + (ix & 1);
-            if (me == am && !(relu_gate && best <= 0.f)) g = dout[(((int64_t)b * Ho + oy) * Wo + ox) * C + c];
+        for (int e = 0; e < V; ++e) {
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+            if (full) {
+                const float v[4] = {x[base + e], x[base + C + e], x[base + (int64_t)W * C + e], x[base + (int64_t)W * C + C + e]};
+                int am = 0;
+                float best = v[0];
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (v[k] > best) { best = v[k]; am = k; }
+                if (!(relu_gate && best <= 0.f)) g[am] = dout[(((int64_t)b * Ho + oy) * Wo + ox) * C + c + e];
+            }
+            dx[base + e] = g[0];
+            if (has_r) dx[base + C + e] = g[1];
+            if (has_d) dx[base + (int64_t)W * C + e] = g[2];
+            if (has_r && has_d) dx[base + (int64_t)W * C + C + e] = g[3];
         }
-        dx[idx] = g;
     }
 }
 extern "C" int tg_maxpool2_bwd(const float* dout, const float* x, int B, int H, int W, int C, int relu_gate, float* dx,
                                tg_stream_t stream) {
     TG_REQUIRE(dout && x && dx && B > 0 && H > 1 && W > 1 && C > 0, "tg_maxpool2_bwd: bad arguments");
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid((int64_t)B * H * W * C, 256)), dim3(256), 0, S(stream), dout, x, B, H, W,
-                       C, relu_gate, dx);
+    const int64_t windows = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((maxpool2_bwd_kernel<4>), dim3(ew_grid(windows * C / 4, 256)), dim3(256), 0, S(stream), dout, x, B, H, W, C,
+                           relu_gate, dx);
+    else
+        hipLaunchKernelGGL((maxpool2_bwd_kernel<1>), dim3(ew_grid(windows * C, 256)), dim3(256), 0, S(stream), dout, x, B, H, W, C,
+                           relu_gate, dx);
     TG_CHECK_LAUNCH("maxpool2_bwd_kernel");
     return TG_OK;
 }

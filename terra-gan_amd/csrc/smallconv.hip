@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void smallconv_slab_reduce(const float* __rest
 
 static int to1_wgrad_blocks(const WgradParams& p) {
     int blocks = cdiv(p.Mpix / 4, 64);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 256) blocks = 256;      // one resident workgroup per CU; keeps the second-stage sum short
     if (blocks < 1) blocks = 1;
     return blocks;
 }

@@ -105,6 +105,26 @@ extern "C" int tg_prof_summary(int kind, double* total_ms, int64_t* launches, do
 // ------------------------------------------------------------------------------------------------
 #include "igemm_params.h"
 
+// Split-K factor with wave quantisation in mind: `slots` workgroups are resident at once (CUs x occupancy); a grid
+// of 1.3 x slots long-running workgroups takes as long as 2 x slots.  Pick the smallest split count whose grid
+// fills at least one round and wastes <= 8 % of its last round, else the most efficient one.
+static int choose_splits(long tiles, int max_splits, int slots) {
+    if (max_splits < 1) max_splits = 1;
+    if (tiles >= 4L * slots) return 1;                 // many rounds already: the tail is small
+    int best = 1;
+    double best_eff = 0.0;
+    for (int sp = 1; sp <= max_splits; ++sp) {
+        const long blocks = tiles * sp;
+        const long rounds = (blocks + slots - 1) / slots;
+        const double eff = (double)blocks / ((double)rounds * slots);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
+        if (blocks >= slots && eff >= 0.92) return sp;
+        if (blocks >= 6L * slots) break;
+    }
+    return best;
+}
+
+
 // XCD-aware work remap (bijective): hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
 // ids b and b+8 share an L2.  Map id -> work index such that each XCD gets a CONTIGUOUS range of work items;
 // callers order work items so that neighbours share operands (same pixels, different channel tiles).
@@ -293,26 +313,36 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
             }
             const float* Ab = As + cur * BM * LDK;
             const float* Bb = Bs + cur * BN * LDK;
+            // operand fragments are double-buffered in registers: the LDS reads of k-group g+1 are issued before the
+            // MFMAs of k-group g, so their latency hides behind 16 MFMAs instead of stalling every group
+            f32x4 a[2][WM], b[2][WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(Ab + (arow + 32 * i) * LDK + ko);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b[0][j] = *reinterpret_cast<const f32x4*>(Bb + (brow + 32 * j) * LDK + ko);
 #pragma unroll
             for (int kg = 0; kg < 4; ++kg) {
                 // a quarter of the next step's global loads rides behind each MFMA group
                 if constexpr (!SCALAR) {
                     if (more) gpart(kg);
                 }
-                f32x4 a[WM], b[WN];
+                if (kg < 3) {
 #pragma unroll
-                for (int i = 0; i < WM; ++i)
-                    a[i] = *reinterpret_cast<const f32x4*>(Ab + (arow + 32 * i) * LDK + kg * 8 + ko);
+                    for (int i = 0; i < WM; ++i)
+                        a[(kg + 1) & 1][i] = *reinterpret_cast<const f32x4*>(Ab + (arow + 32 * i) * LDK + (kg + 1) * 8 + ko);
 #pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    b[j] = *reinterpret_cast<const f32x4*>(Bb + (brow + 32 * j) * LDK + kg * 8 + ko);
+                    for (int j = 0; j < WN; ++j)
+                        b[(kg + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Bb + (brow + 32 * j) * LDK + (kg + 1) * 8 + ko);
+                }
+                __builtin_amdgcn_sched_barrier(0);     // keep the prefetch (LDS + global) ABOVE this group's MFMAs
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
                         for (int j = 0; j < WN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg & 1][i][e], b[kg & 1][j][e], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (more) sstore(cur ^ 1);
             __syncthreads();
@@ -556,20 +586,30 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
                 const int ty = tap / p.TW, tx = tap - ty * p.TW;
                 const int toff = ((p.sy0 + ty * p.tstep - q.sy_min) * q.PW + (p.sx0 + tx * p.tstep - q.sx_min)) * LDK;
                 const float* Bb = Bs + cur * BN * LDK;
+                f32x4 a[2][WM], bb[2][WN];       // register double-buffered fragments (see igemm_kernel)
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(Ps + abase[i] + toff);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bb[0][j] = *reinterpret_cast<const f32x4*>(Bb + (brow + 32 * j) * LDK + ko);
 #pragma unroll
                 for (int kg = 0; kg < 4; ++kg) {
-                    f32x4 a[WM], bb[WN];
+                    if (kg < 3) {
 #pragma unroll
-                    for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ps + abase[i] + toff + kg * 8);
+                        for (int i = 0; i < WM; ++i)
+                            a[(kg + 1) & 1][i] = *reinterpret_cast<const f32x4*>(Ps + abase[i] + toff + (kg + 1) * 8);
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) bb[j] = *reinterpret_cast<const f32x4*>(Bb + (brow + 32 * j) * LDK + kg * 8 + ko);
+                        for (int j = 0; j < WN; ++j)
+                            bb[(kg + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Bb + (brow + 32 * j) * LDK + (kg + 1) * 8 + ko);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int i = 0; i < WM; ++i)
 #pragma unroll
                             for (int j = 0; j < WN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], bb[j][e], acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg & 1][i][e], bb[kg & 1][j][e], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (next_chunk) {
                     __syncthreads();        // every wave is done with the current patch
@@ -677,13 +717,11 @@ static bool try_pgemm(IGemmParams& p, size_t ws_floats_avail, hipStream_t s, int
     // split over channel chunks when the grid is small
     const long tiles = (long)q.tiles_x * q.tiles_y * p.B * cdiv(p.N, n64 ? 64 : 128);
     int splits = 1;
-    if (tiles < 384 && p.nchunks >= 4) {
-        splits = (int)((768 + tiles - 1) / tiles);
-        if (splits > p.nchunks / 2) splits = p.nchunks / 2;
-        if (splits > 32) splits = 32;
-        if (splits < 1) splits = 1;
+    if (p.nchunks >= 4) {
+        int smax = p.nchunks / 2 < 32 ? p.nchunks / 2 : 32;
+        while (smax > 1 && (size_t)smax * p.M * p.N > ws_floats_avail) --smax;
+        splits = choose_splits(tiles, smax, 512);
     }
-    while (splits > 1 && (size_t)splits * p.M * p.N > ws_floats_avail) --splits;
     q.chunks_per_split = cdiv(p.nchunks, splits);
     p.splits = cdiv(p.nchunks, q.chunks_per_split);
     if (n64) *rc = launch_pgemm_cfg<16, 16, 4, 1, 2, 2, 12>(p, q, s);
@@ -698,13 +736,11 @@ static void plan_splits(IGemmParams& p, size_t ws_floats_avail) {
     const int bn = pick_bn(p.N);
     const long tiles = (long)cdiv(p.M, 128) * cdiv(p.N, bn);
     int splits = 1;
-    if (tiles < 384 && p.T >= 8) {
-        splits = (int)((768 + tiles - 1) / tiles);
-        if (splits > p.T / 4) splits = p.T / 4;
-        if (splits > 64) splits = 64;
-        if (splits < 1) splits = 1;
+    if (p.T >= 8) {
+        int smax = p.T / 4 < 64 ? p.T / 4 : 64;
+        while (smax > 1 && (size_t)smax * p.M * p.N > ws_floats_avail) --smax;
+        splits = choose_splits(tiles, smax, 512);
     }
-    while (splits > 1 && (size_t)splits * p.M * p.N > ws_floats_avail) --splits;
     p.steps_per_split = cdiv(p.T > 0 ? p.T : 1, splits);
     p.splits = p.T > 0 ? cdiv(p.T, p.steps_per_split) : 1;
 }
@@ -920,6 +956,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         py[i] = tt % p.Ho;
         pb[i] = tt / p.Ho;
     }
+    // row-segment mode: the step's 32 pixels share (b, oy); wave-uniform counters, advanced incrementally
+    int rs_ox0 = (t_begin * BK) % p.Wo, rs_oy = ((t_begin * BK) / p.Wo) % p.Ho, rs_b = (t_begin * BK) / p.Wo / p.Ho;
 
     auto gload = [&](int t) {
         const int mbase = t * BK;
@@ -945,6 +983,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
             }
         }
         // B' = tap-shifted, masked input rows
+        if (!SCALAR_B && p.rowseg) {
+            const int iy = rs_oy * p.stride + bky[0];
+            const bool vy = bv[0] && iy >= 0 && iy < p.H && mbase < p.Mpix;
+            const size_t rowoff = ((size_t)rs_b * p.H + (vy ? iy : 0)) * p.W;
+            const int ixb = rs_ox0 * p.stride + bkx[0];
+#pragma unroll
+            for (int i = 0; i < B_V; ++i) {
+                const int ix = ixb + ((tid >> 5) + 8 * i) * p.stride;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (vy && ix >= 0 && ix < p.W) {
+                    const size_t pix = rowoff + ix;
+                    v = *reinterpret_cast<const f32x4*>(p.x + pix * p.C + bc[0]);
+                    if (p.amask) v *= p.amask[pix];
+                }
+                rbv[i] = v;
+            }
+            rs_ox0 += BK;
+            if (rs_ox0 >= p.Wo) {
+                rs_ox0 = 0;
+                if (++rs_oy == p.Ho) { rs_oy = 0; ++rs_b; }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < B_V; ++i) {
             int krow = (tid >> 5) + 8 * i;
@@ -1028,18 +1089,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
             if (more) gload(t + 1);
             const float* Ab = As + cur * BK * BM;
             const float* Bb = Bs + cur * BK * BN;
+            // fragments double-buffered in registers: reads for k-pair kk+1 are in flight during the MFMAs of pair kk
+            float a[2][WM], b[2][WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[0][i] = Ab[kh * BM + acol + 32 * i];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b[0][j] = Bb[kh * BN + bcol + 32 * j];
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
-                float a[WM], b[WN];
+                if (kk + 1 < BK / 2) {
 #pragma unroll
-                for (int i = 0; i < WM; ++i) a[i] = Ab[(2 * kk + kh) * BM + acol + 32 * i];
+                    for (int i = 0; i < WM; ++i) a[(kk + 1) & 1][i] = Ab[(2 * kk + 2 + kh) * BM + acol + 32 * i];
 #pragma unroll
-                for (int j = 0; j < WN; ++j) b[j] = Bb[(2 * kk + kh) * BN + bcol + 32 * j];
+                    for (int j = 0; j < WN; ++j) b[(kk + 1) & 1][j] = Bb[(2 * kk + 2 + kh) * BN + bcol + 32 * j];
+                }
+                __builtin_amdgcn_sched_barrier(0);     // keep the prefetch reads ABOVE this pair's MFMAs
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (more) sstore(cur ^ 1);
             __syncthreads();
@@ -1087,6 +1157,7 @@ static int launch_wgrad_cfg(const WgradParams& p, hipStream_t s) {
         attr_done = true;
     }
     WgradParams pp = p;
+    pp.rowseg = (p.Wo % 32 == 0 && !SB && !getenv("TG_NO_ROWSEG")) ? 1 : 0;
     pp.nx = cdiv(p.Ktot, BN);
     pp.ny = cdiv(p.Cout, BM);
     dim3 grid(pp.nx * pp.ny * p.splits);
@@ -1111,10 +1182,8 @@ static void wgrad_plan(const TgConv* g, int* splits, int* steps_per_split, int* 
     const int bm = wgrad_bm(g);
     const long tiles = (long)cdiv(g->Cout, bm) * cdiv(Ktot, 128);
     *T = cdiv(Mpix, 32);
-    int sp = (int)((1024 + tiles - 1) / tiles);
-    if (sp > cdiv(*T, 4)) sp = cdiv(*T, 4);
-    if (sp > 512) sp = 512;
-    if (sp < 1) sp = 1;
+    int smax = cdiv(*T, 4) < 512 ? cdiv(*T, 4) : 512;
+    int sp = choose_splits(tiles, smax, 256 * (bm == 128 ? 2 : 3));
     *steps_per_split = cdiv(*T, sp);
     *splits = cdiv(*T, *steps_per_split);
 }

@@ -38,6 +38,7 @@ struct WgradParams {
     int B, H, W, C, Ho, Wo, Cout, k, stride, pad;
     int Mpix, Ktot, T, splits, steps_per_split;
     int nx, ny;   // N' tiles, Cout tiles (grid is launched flat: nx*ny*splits workgroups)
+    int rowseg;   // Wo % 32 == 0: every 32-pixel K step lies inside one output row (cheap gather addressing)
 };
 
 // smallconv.hip: bandwidth-bound special cases that would waste >95% of an MFMA tile

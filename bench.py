@@ -134,28 +134,50 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
-        # instrumented pass (outside the timed region): hipEvents around every MFMA conv launch
+        # instrumented pass (outside the timed region): hipEvents around every MFMA conv launch, on its launch stream
+        import csv
+        import tempfile
+        nprobe = 2
         lib.tg_prof_enable(1)
-        run(2)
+        run(nprobe)
         torch.cuda.synchronize()
         lib.tg_prof_enable(0)
-        if args.prof_dump:
-            lib.tg_prof_dump(args.prof_dump.encode())
-        ms0, n0, fl0, by0 = prof_summary(lib, 0)
-        ms1, n1, fl1, by1 = prof_summary(lib, 1)
-        ms2, n2, fl2, by2 = prof_summary(lib, 2)
-        ach = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "igemm_kernel (fp32 MFMA implicit-GEMM conv fwd/dgrad)",
+        dump = args.prof_dump or os.path.join(tempfile.gettempdir(), f"tg_prof_{os.getpid()}.csv")
+        lib.tg_prof_dump(dump.encode())
+        rows = list(csv.DictReader(open(dump)))
+        for kind in (0, 1, 2):
+            prof_summary(lib, kind)                       # consume the records
+
+        def agg(pred):
+            sel = [r for r in rows if pred(r)]
+            ms = sum(float(r["ms"]) for r in sel)
+            return ms, len(sel), sum(float(r["gflop"]) for r in sel) * 1e9, sum(float(r["alg_mb"]) for r in sel) * 1e6
+
+        # dominant kernel symbol = pgemm_kernel<8,16,2,2,2,2,7> (patch-staged implicit GEMM, 128x128 tile): cfg 1128
+        ms, n, fl, by = agg(lambda r: r["kind"] == "0" and r["cfg"] == "1128")
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath):       # offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+            tj = json.load(open(tpath))
+            key = [k for k in tj if "pgemm_kernel<8, 16" in k]
+            traffic = round(tj[key[0]]["hbm_bytes_per_launch"]) if key else None
+        roofline = {"bound": "mfma", "kernel": "pgemm_kernel<8,16,2,2,2,2,7> (fp32-MFMA patch-staged implicit-GEMM conv fwd/dgrad, 128x128 tile)",
                     "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": n0 // 2, "avg_launch_ms": round(ms0 / max(n0, 1), 4),
-                    "gflop_per_launch": round(fl0 / max(n0, 1) / 1e9, 3), "kernel_ms_per_step": round(ms0 / 2, 3),
-                    "hbm_alg_GBps": round(by0 / (ms0 * 1e-3) / 1e9, 1) if ms0 > 0 else 0.0,
-                    "wgrad": {"achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else 0.0,
-                              "launches_per_step": n1 // 2, "kernel_ms_per_step": round(ms1 / 2, 3),
-                              "hbm_alg_GBps": round(by1 / (ms1 * 1e-3) / 1e9, 1) if ms1 > 0 else 0.0},
-                    "smallconv_1ch": {"bound": "hbm", "launches_per_step": n2 // 2, "kernel_ms_per_step": round(ms2 / 2, 3),
-                                      "hbm_alg_GBps": round(by2 / (ms2 * 1e-3) / 1e9, 1) if ms2 > 0 else 0.0}}
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "launches_per_step": n // nprobe, "avg_launch_ms": round(ms / max(n, 1), 4),
+                    "gflop_per_launch": round(fl / max(n, 1) / 1e9, 3), "alg_bytes_per_launch": round(by / max(n, 1)),
+                    "kernel_ms_per_step": round(ms / nprobe, 3)}
+        extra = {}
+        for name, pred in [("all_conv_fwd_dgrad_mfma", lambda r: r["kind"] == "0"),
+                           ("pgemm_256x64_tile", lambda r: r["kind"] == "0" and r["cfg"] == "1064"),
+                           ("wgrad_mfma", lambda r: r["kind"] == "1"),
+                           ("one_channel_convs_hbm", lambda r: r["kind"] == "2")]:
+            ms_, n_, fl_, by_ = agg(pred)
+            if ms_ > 0:
+                extra[name] = {"kernel_ms_per_step": round(ms_ / nprobe, 3), "launches_per_step": n_ // nprobe,
+                               "TFLOPs": round(fl_ / (ms_ * 1e-3) / 1e12, 2), "alg_GBps": round(by_ / (ms_ * 1e-3) / 1e9, 1)}
+        roofline["other_kernels"] = extra
     if world > 1:
         dist.barrier()
 

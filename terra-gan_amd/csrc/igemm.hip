@@ -442,11 +442,19 @@ static int launch_igemm_cfg(const IGemmParams& p, hipStream_t s) {
 // A fragments straight from it at a shifted base -- 9x fewer A-side global loads and index math for a
 // 3x3 conv than gathering per tap.  Only the weight tile streams per (chunk, tap), double-buffered.
 // ------------------------------------------------------------------------------------------------
+// One output-grid "class": a whole stride-1 problem, or one parity class of a strided dgrad.  Up to 4 classes
+// (stride 2) share one launch so that the grid fills the chip without split-K.
+struct ClassGeom {
+    int OH, OW, dy0, dx0;                // output grid and its placement in dst
+    int ky0, kx0, TH, TW, sy0, sx0;      // taps of this class
+    int tiles_x, tiles_y;                // output tiles per image
+    int PH, PW;                          // patch size in source pixels
+    int sy_min, sx_min;                  // min over taps of (sy0 + ty*tstep), (sx0 + tx*tstep)
+    int work_begin;                      // first flat work item (patch tile x N tile) of this class
+};
 struct PatchGeom {
-    int tiles_x, tiles_y;   // output tiles per image
-    int PH, PW;             // patch size in source pixels
-    int sy_min, sx_min;     // min over taps of (sy0 + ty*tstep), (sx0 + tx*tstep)
-    int chunks_per_split;
+    int ncls, total_work, chunks_per_split;
+    ClassGeom c[4];
 };
 
 template <int TH_, int TW_, int WAVES_M, int WAVES_N, int WM, int WN, int MAXPL>
@@ -461,18 +469,22 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int kc = tid & 7, r0 = tid >> 3;
-    // flat (patch tile, N tile) index, XCD-remapped so the N tiles of one patch share an L2
+    // flat (class, patch tile, N tile) index, XCD-remapped so the N tiles of one patch share an L2
     const int nty = cdiv_dev(p.N, BN);
-    const int work = xcd_remap(blockIdx.x, q.tiles_x * q.tiles_y * p.B * nty);
+    int work = xcd_remap(blockIdx.x, q.total_work);
+    int ci = 0;
+    while (ci + 1 < q.ncls && work >= q.c[ci + 1].work_begin) ++ci;
+    const ClassGeom g = q.c[ci];
+    work -= g.work_begin;
     const int n0 = (work % nty) * BN;
     int tile = work / nty;
-    const int txi = tile % q.tiles_x;
-    tile /= q.tiles_x;
-    const int tyi = tile % q.tiles_y;
-    const int b = tile / q.tiles_y;
+    const int txi = tile % g.tiles_x;
+    tile /= g.tiles_x;
+    const int tyi = tile % g.tiles_y;
+    const int b = tile / g.tiles_y;
     const int oy0 = tyi * TH_, ox0 = txi * TW_;
-    const int py0 = oy0 * p.ss + q.sy_min, px0 = ox0 * p.ss + q.sx_min;
-    const int ppix = q.PH * q.PW;
+    const int py0 = oy0 * p.ss + g.sy_min, px0 = ox0 * p.ss + g.sx_min;
+    const int ppix = g.PH * g.PW;
 
     // patch slots owned by this thread: fixed for the whole K loop
     uint32_t poff[MAXPL];
@@ -484,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
         poff[i] = 0;
         pmul[i] = 0.f;
         if (pp < ppix) {
-            const int py = pp / q.PW, px = pp - py * q.PW;
+            const int py = pp / g.PW, px = pp - py * g.PW;
             const int iy = py0 + py, ix = px0 + px;
             if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) {
                 const uint32_t pix = ((uint32_t)b * p.IH + iy) * p.IW + ix;
@@ -506,11 +518,11 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int r = (wm * WM + i) * 32 + (lane & 31);
-        abase[i] = ((r / TW_) * p.ss * q.PW + (r % TW_) * p.ss) * LDK + 4 * (lane >> 5);
+        abase[i] = ((r / TW_) * p.ss * g.PW + (r % TW_) * p.ss) * LDK + 4 * (lane >> 5);
     }
     const int brow = wn * WN * 32 + (lane & 31);
     const int ko = 4 * (lane >> 5);
-    const int ntaps = p.TH * p.TW;
+    const int ntaps = g.TH * g.TW;
     const int c_begin = blockIdx.z * q.chunks_per_split;
     const int c_end = min(p.nchunks, c_begin + q.chunks_per_split);
 
@@ -540,8 +552,8 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
     };
     constexpr int NBATCH = PREFETCH ? 1 : 2;
     auto wload = [&](int c, int tap) {
-        const int ty = tap / p.TW, tx = tap - ty * p.TW;
-        const uint32_t widx = (uint32_t)(((p.ky0 + ty * p.kstep) * p.KW + (p.kx0 + tx * p.kstep)) * p.C + c * 32);
+        const int ty = tap / g.TW, tx = tap - ty * g.TW;
+        const uint32_t widx = (uint32_t)(((g.ky0 + ty * p.kstep) * p.KW + (g.kx0 + tx * p.kstep)) * p.C + c * 32);
         const bool cv = c * 32 + 4 * kc < p.C;
 #pragma unroll
         for (int j = 0; j < B_LOADS; ++j) {
@@ -583,8 +595,8 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
                 if constexpr (PREFETCH) {
                     if (next_chunk) pload(c + 1, 0);
                 }
-                const int ty = tap / p.TW, tx = tap - ty * p.TW;
-                const int toff = ((p.sy0 + ty * p.tstep - q.sy_min) * q.PW + (p.sx0 + tx * p.tstep - q.sx_min)) * LDK;
+                const int ty = tap / g.TW, tx = tap - ty * g.TW;
+                const int toff = ((g.sy0 + ty * p.tstep - g.sy_min) * g.PW + (g.sx0 + tx * p.tstep - g.sx_min)) * LDK;
                 const float* Bb = Bs + cur * BN * LDK;
                 f32x4 a[2][WM], bb[2][WN];       // register double-buffered fragments (see igemm_kernel)
 #pragma unroll
@@ -637,16 +649,16 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
         for (int r = 0; r < 16; ++r) {
             const int row = (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int oy = oy0 + row / TW_, ox = ox0 + row % TW_;
-            if (oy >= p.OH || ox >= p.OW) continue;
+            if (oy >= g.OH || ox >= g.OW) continue;
             if (p.splits > 1) {
-                const size_t m = ((size_t)b * p.OH + oy) * p.OW + ox;
+                const size_t m = ((size_t)b * g.OH + oy) * g.OW + ox;
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
                     const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
                     if (n < p.N) p.ws[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
                 }
             } else {
-                const size_t pix = ((size_t)b * p.DH + (oy * p.ds + p.dy0)) * p.DW + (ox * p.ds + p.dx0);
+                const size_t pix = ((size_t)b * p.DH + (oy * p.ds + g.dy0)) * p.DW + (ox * p.ds + g.dx0);
                 const float rs = p.rowscale ? p.rowscale[pix] : 1.f;
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
@@ -667,9 +679,11 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
 }
 
 template <int TH_, int TW_, int WAVES_M, int WAVES_N, int WM, int WN, int MAXPL>
-static int launch_pgemm_cfg(const IGemmParams& p, const PatchGeom& q, hipStream_t s) {
+static int launch_pgemm_cfg(const IGemmParams& p, const PatchGeom& q, double flops, double bytes, int Mtot, hipStream_t s) {
     constexpr int BN = WAVES_N * WN * 32;
-    const size_t lds = ((size_t)2 * BN + (size_t)q.PH * q.PW) * 36 * sizeof(float);
+    int ppix = 0;
+    for (int i = 0; i < q.ncls; ++i) ppix = q.c[i].PH * q.c[i].PW > ppix ? q.c[i].PH * q.c[i].PW : ppix;
+    const size_t lds = ((size_t)2 * BN + (size_t)ppix) * 36 * sizeof(float);
     static size_t attr_lds = 0;
     auto kern = pgemm_kernel<TH_, TW_, WAVES_M, WAVES_N, WM, WN, MAXPL>;
     if (lds > attr_lds) {
@@ -680,11 +694,9 @@ static int launch_pgemm_cfg(const IGemmParams& p, const PatchGeom& q, hipStream_
         }
         attr_lds = lds;
     }
-    dim3 grid(q.tiles_x * q.tiles_y * p.B * cdiv(p.N, BN), 1, p.splits);
+    dim3 grid(q.total_work, 1, p.splits);
     {
-        const double by = 4.0 * ((double)p.B * p.IH * p.IW * p.C + (double)p.M + (double)p.N * p.Ktot + (double)p.M * p.N +
-                                 (p.amask ? (double)p.B * p.IH * p.IW : 0.0));
-        ProfScope ps(s, 0, 2.0 * p.M * (double)p.N * p.Ktot, by, p.M, p.N, p.Ktot, p.C, p.splits, 1000 + BN);
+        ProfScope ps(s, 0, flops, bytes, Mtot, p.N, p.Ktot, p.C, p.splits, 1000 + BN);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p, q);
     }
     TG_CHECK_LAUNCH("pgemm_kernel");
@@ -695,37 +707,65 @@ static int launch_pgemm_cfg(const IGemmParams& p, const PatchGeom& q, hipStream_
     return TG_OK;
 }
 
-// Eligibility + planning of the patch kernel.  Returns true (and launches) when it applies.
-static bool try_pgemm(IGemmParams& p, size_t ws_floats_avail, hipStream_t s, int* rc) {
-    if (getenv("TG_NO_PGEMM")) return false;
+static bool pgemm_class_ok(const IGemmParams& p) {
     if (p.ss != 1 || (p.C % 32) != 0 || p.TH < 1 || p.TW < 1 || p.TH > 4 || p.TW > 4) return false;
     if (p.OW < 16 || p.OH < 8) return false;
     const bool n64 = !(p.N >= 128 && p.N % 128 == 0);
-    if (n64 && p.N < 48) return false;                      // tiny N: dedicated kernels / v1
-    const int th = (n64 && p.OH >= 16) ? 16 : 8, tw = 16;
-    if (n64 && th != 16) return false;
-    PatchGeom q;
-    q.tiles_x = cdiv(p.OW, tw);
-    q.tiles_y = cdiv(p.OH, th);
-    const int sy_a = p.sy0, sy_b = p.sy0 + (p.TH - 1) * p.tstep, sx_a = p.sx0, sx_b = p.sx0 + (p.TW - 1) * p.tstep;
-    q.sy_min = sy_a < sy_b ? sy_a : sy_b;
-    q.sx_min = sx_a < sx_b ? sx_a : sx_b;
-    q.PH = th + p.TH - 1;
-    q.PW = tw + p.TW - 1;
+    if (n64 && (p.N < 48 || p.OH < 16)) return false;       // tiny N: dedicated kernels / v1
+    return true;
+}
+
+// Patch kernel for `ncls` classes (1 = ordinary conv / stride-1 dgrad, 4 = the parity classes of a stride-2 dgrad
+// merged into one launch).  Returns true (and launches) when it applies.
+static bool try_pgemm(IGemmParams* ps, int ncls, size_t ws_floats_avail, hipStream_t s, int* rc) {
+    if (getenv("TG_NO_PGEMM") || ncls < 1 || ncls > 4) return false;
+    for (int i = 0; i < ncls; ++i)
+        if (!pgemm_class_ok(ps[i])) return false;
+    IGemmParams& p = ps[0];
+    const bool n64 = !(p.N >= 128 && p.N % 128 == 0);
+    const int th = n64 ? 16 : 8, tw = 16, bn = n64 ? 64 : 128;
+    const int nty = cdiv(p.N, bn);
+    PatchGeom q = {};
+    q.ncls = ncls;
+    int work = 0, Mtot = 0;
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < ncls; ++i) {
+        const IGemmParams& pc = ps[i];
+        ClassGeom& c = q.c[i];
+        c.OH = pc.OH; c.OW = pc.OW; c.dy0 = pc.dy0; c.dx0 = pc.dx0;
+        c.ky0 = pc.ky0; c.kx0 = pc.kx0; c.TH = pc.TH; c.TW = pc.TW; c.sy0 = pc.sy0; c.sx0 = pc.sx0;
+        c.tiles_x = cdiv(pc.OW, tw);
+        c.tiles_y = cdiv(pc.OH, th);
+        const int sy_b = pc.sy0 + (pc.TH - 1) * pc.tstep, sx_b = pc.sx0 + (pc.TW - 1) * pc.tstep;
+        c.sy_min = pc.sy0 < sy_b ? pc.sy0 : sy_b;
+        c.sx_min = pc.sx0 < sx_b ? pc.sx0 : sx_b;
+        c.PH = th + pc.TH - 1;
+        c.PW = tw + pc.TW - 1;
+        c.work_begin = work;
+        work += c.tiles_x * c.tiles_y * pc.B * nty;
+        Mtot += pc.M;
+        const double kt = (double)pc.TH * pc.TW * pc.C;
+        flops += 2.0 * pc.M * (double)pc.N * kt;
+        bytes += 4.0 * ((double)pc.M * pc.N + (double)pc.N * kt);
+    }
+    bytes += 4.0 * ((double)p.B * p.IH * p.IW * p.C + (double)Mtot + (p.amask ? (double)p.B * p.IH * p.IW : 0.0));
+    q.total_work = work;
     p.Ktot = p.TH * p.TW * p.C;
     p.nchunks = p.C / 32;
-    // split over channel chunks when the grid is small
-    const long tiles = (long)q.tiles_x * q.tiles_y * p.B * cdiv(p.N, n64 ? 64 : 128);
     int splits = 1;
-    if (p.nchunks >= 4) {
-        int smax = p.nchunks / 2 < 32 ? p.nchunks / 2 : 32;
-        while (smax > 1 && (size_t)smax * p.M * p.N > ws_floats_avail) --smax;
-        splits = choose_splits(tiles, smax, 512);
+    if (ncls == 1) {
+        if (p.nchunks >= 4) {
+            int smax = p.nchunks / 2 < 32 ? p.nchunks / 2 : 32;
+            while (smax > 1 && (size_t)smax * p.M * p.N > ws_floats_avail) --smax;
+            splits = choose_splits(work, smax, 512);
+        }
+    } else if (work < 384) {
+        return false;           // merged launch has no split-K: too small a grid goes class by class instead
     }
     q.chunks_per_split = cdiv(p.nchunks, splits);
     p.splits = cdiv(p.nchunks, q.chunks_per_split);
-    if (n64) *rc = launch_pgemm_cfg<16, 16, 4, 1, 2, 2, 12>(p, q, s);
-    else *rc = launch_pgemm_cfg<8, 16, 2, 2, 2, 2, 7>(p, q, s);
+    if (n64) *rc = launch_pgemm_cfg<16, 16, 4, 1, 2, 2, 12>(p, q, flops, bytes, Mtot, s);
+    else *rc = launch_pgemm_cfg<8, 16, 2, 2, 2, 2, 7>(p, q, flops, bytes, Mtot, s);
     return true;
 }
 
@@ -756,7 +796,7 @@ static int launch_igemm(IGemmParams& p, hipStream_t s, size_t ws_floats_avail = 
     }
     {
         int rc = TG_OK;
-        if (try_pgemm(p, ws_floats_avail, s, &rc)) return rc;
+        if (try_pgemm(&p, 1, ws_floats_avail, s, &rc)) return rc;
     }
     const bool scalar = (p.C % 4) != 0;
     p.Ktot = p.TH * p.TW * p.C;
@@ -874,6 +914,9 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, con
     const size_t ws2_floats = ws_bytes / sizeof(float) - wt_floats;
 
     const int st = g->stride;
+    IGemmParams cls[4];
+    int ncls = 0;
+    const bool mergeable = st * st <= 4;
     for (int py = 0; py < st; ++py) {
         for (int px = 0; px < st; ++px) {
             IGemmParams p = {};
@@ -894,8 +937,25 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, con
             p.gate = gate; p.gate_act = gate_act; p.gate_slope = gate_slope;
             p.Ktot = p.TH * p.TW * p.C; p.nchunks = cdiv(p.C, 32);
             p.T = (p.C % 4) ? cdiv(p.Ktot, 32) : p.TH * p.TW * p.nchunks;
-            plan_splits(p, ws2_floats);
-            rc = launch_igemm(p, s, ws2_floats);
+            if (mergeable) {
+                cls[ncls++] = p;
+            } else {
+                plan_splits(p, ws2_floats);
+                rc = launch_igemm(p, s, ws2_floats);
+                if (rc) return rc;
+            }
+        }
+    }
+    if (mergeable && ncls > 0) {
+        // the parity classes of a stride-2 dgrad go out as ONE patch-kernel launch when they qualify
+        if (ncls > 1 && !smallconv_fwd_applies(cls[0])) {
+            IGemmParams tmp[4];
+            for (int i = 0; i < ncls; ++i) tmp[i] = cls[i];
+            if (try_pgemm(tmp, ncls, ws2_floats, s, &rc)) return rc;
+        }
+        for (int i = 0; i < ncls; ++i) {
+            plan_splits(cls[i], ws2_floats);
+            rc = launch_igemm(cls[i], s, ws2_floats);
             if (rc) return rc;
         }
     }

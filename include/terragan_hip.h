@@ -179,6 +179,20 @@ int tg_bce_logits(const float* z, int64_t n, float target, float coef, const flo
 int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
             float beta2, float eps, int step, float grad_scale, tg_stream_t stream);
 
+/* Multi-tensor form: ONE launch over a device-resident table of segments (whole parameter tensors) and a
+ * device-resident work list of int32 pairs (segment index, chunk index); chunk c of a segment covers elements
+ * [c*chunk_elems, min(n, (c+1)*chunk_elems)).  All segments share lr/betas/eps/step. */
+typedef struct TgAdamSeg {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+} TgAdamSeg;
+int tg_adam_multi(const TgAdamSeg* segs_dev, const int32_t* work_dev, int nwork, int chunk_elems,
+                  float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                  tg_stream_t stream);
+
 /* y = a*x + b*y elementwise (gradient accumulation / scaling glue). */
 int tg_axpby(const float* x, float a, float b, float* y, int64_t n, tg_stream_t stream);
 /* out = a*x + b*y of two device scalars/vectors into a third (loss totals). */

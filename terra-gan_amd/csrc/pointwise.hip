@@ -1054,6 +1054,35 @@ extern "C" int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, 
     return TG_OK;
 }
 
+// multi-tensor Adam: one launch walks a device-resident table of (p, g, m, v, n) segments; work item w covers
+// elements [chunk*chunk_elems, ...) of segment seg (both packed in `work`)
+__global__ __launch_bounds__(256) void adam_multi_kernel(const TgAdamSeg* __restrict__ segs, const int32_t* __restrict__ work,
+                                                         int chunk_elems, float one_minus_b1, float b2, float one_minus_b2,
+                                                         float step_size, float inv_bc2_sqrt, float eps, float grad_scale) {
+    const int seg = work[2 * blockIdx.x], chunk = work[2 * blockIdx.x + 1];
+    const TgAdamSeg sg = segs[seg];
+    const int64_t begin = (int64_t)chunk * chunk_elems;
+    const int64_t end = min(sg.n, begin + chunk_elems);
+    for (int64_t i = begin + threadIdx.x; i < end; i += 256) {
+        const float gr = sg.g[i] * grad_scale;
+        const float mi = sg.m[i] + one_minus_b1 * (gr - sg.m[i]);
+        const float vi = sg.v[i] * b2 + one_minus_b2 * gr * gr;
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        sg.m[i] = mi;
+        sg.v[i] = vi;
+        sg.p[i] = sg.p[i] - step_size * (mi / denom);
+    }
+}
+extern "C" int tg_adam_multi(const TgAdamSeg* segs_dev, const int32_t* work_dev, int nwork, int chunk_elems, float lr, float beta1,
+                             float beta2, float eps, int step, float grad_scale, tg_stream_t stream) {
+    TG_REQUIRE(segs_dev && work_dev && nwork > 0 && chunk_elems > 0 && step >= 1, "tg_adam_multi: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(nwork), dim3(256), 0, S(stream), segs_dev, work_dev, chunk_elems, 1.f - beta1, beta2,
+                       1.f - beta2, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps, grad_scale);
+    TG_CHECK_LAUNCH("adam_multi_kernel");
+    return TG_OK;
+}
+
 __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, float a, float b, float* __restrict__ y,
                                                     int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)

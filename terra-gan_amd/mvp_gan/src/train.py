@@ -32,6 +32,7 @@ from torch.utils.data import DataLoader
 
 from tg_hip import engine as E
 from tg_hip import ops as O
+from tg_hip.gradbuf import grad_buffers
 
 from mvp_gan import ExperimentTracker  # noqa: F401  (None when tracking is unavailable)
 from .models._common import as_bhw, require_hip
@@ -63,26 +64,29 @@ def hip_adam_step(optimizer, grad_scale=1.0, buckets=None):
         for p in group["params"]:
             hyper[p] = (float(group["lr"]), group["betas"][0], group["betas"][1], float(group["eps"]))
 
-    def _update(p):
-        if p.grad is None or p not in hyper:
-            return
-        lr, b1, b2, eps = hyper[p]
-        st = optimizer.state[p]
-        if len(st) == 0:
-            st["step"] = torch.tensor(0.0, dtype=torch.float32)
-            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        st["step"] += 1
-        O.adam_(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], lr, b1, b2, eps, int(st["step"]), grad_scale)
+    def _update(plist):
+        """One multi-tensor launch per (hyper-parameter set, step count) group -- normally a single group."""
+        groups = {}
+        for p in plist:
+            if p.grad is None or p not in hyper:
+                continue
+            st = optimizer.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+            groups.setdefault(hyper[p] + (int(st["step"]),), []).append((p, st))
+        for (lr, b1, b2, eps, step), items in groups.items():
+            O.adam_multi_([p.data for p, _ in items], [p.grad for p, _ in items], [st["exp_avg"] for _, st in items],
+                          [st["exp_avg_sq"] for _, st in items], lr, b1, b2, eps, step, grad_scale)
 
     if buckets is None:
-        for p in hyper:
-            _update(p)
+        _update(list(hyper))
     else:
         for b in buckets:
             b.wait()
-            for p in b.params:
-                _update(p)
+            _update(b.params)
 
 
 def _assign_grads(module, grads):
@@ -112,11 +116,15 @@ def train_step(generator, discriminator, criterion, optimizer_G, optimizer_D, re
     g_total = O.lincomb(g_loss, 1.0, g_adv, 1.0)                             # train.py:204
     _none, dgen_adv = E.discriminator_backward(DP, dctx_fake, dlogits, want_wgrad=False, want_dimg=True)
     O.axpby_(dgen_adv.reshape(B, H, W), 1.0, 1.0, dgen)
-    ggrads, _ = E.generator_backward(GP, gctx, dgen)                         # train.py:206
+    ggrads, _ = E.generator_backward(GP, gctx, dgen, gbuf=grad_buffers(generator).views)   # train.py:206
     del gctx
     _assign_grads(generator, ggrads)
+    # Data parallel: the generator's 103 MB all-reduce is launched now and runs on RCCL's stream underneath the whole
+    # discriminator step below, which needs neither the reduced gradients nor the updated generator weights
+    # (it consumes gen.detach() and D's own parameters); optimizer_G.step() is applied after it.  Same results.
     gb = grad_sync(generator, "G") if grad_sync is not None else None
-    hip_adam_step(optimizer_G, grad_sync.grad_scale if grad_sync is not None else 1.0, gb)     # train.py:207
+    if grad_sync is None:
+        hip_adam_step(optimizer_G)                                           # train.py:207
 
     # ---- discriminator ----------------------------------------------------------------------------
     optimizer_D.zero_grad()                                                  # train.py:210
@@ -128,13 +136,18 @@ def train_step(generator, discriminator, criterion, optimizer_G, optimizer_D, re
     real_loss, dl_real = O.bce_logits(real_logits, 1.0, coef=0.5)            # train.py:215,217
     fake_loss, dl_fake = O.bce_logits(fake_logits, 0.0, coef=0.5)            # train.py:216,217
     d_loss = O.lincomb(real_loss, 0.5, fake_loss, 0.5)
-    dg_real, _ = E.discriminator_backward(DP, dctx_real, dl_real, want_wgrad=True)         # train.py:218
+    dg_real, _ = E.discriminator_backward(DP, dctx_real, dl_real, want_wgrad=True,
+                                          gbuf=grad_buffers(discriminator).views)          # train.py:218
     dg_fake, _ = E.discriminator_backward(DP, dctx_fake, dl_fake, want_wgrad=True)
     for k, g in dg_real.items():
         O.axpby_(dg_fake[k], 1.0, 1.0, g)
     _assign_grads(discriminator, dg_real)
-    db = grad_sync(discriminator, "D") if grad_sync is not None else None
-    hip_adam_step(optimizer_D, grad_sync.grad_scale if grad_sync is not None else 1.0, db)     # train.py:219
+    if grad_sync is not None:
+        db = grad_sync(discriminator, "D")
+        hip_adam_step(optimizer_G, grad_sync.grad_scale, gb)                 # train.py:207 (deferred, see above)
+        hip_adam_step(optimizer_D, grad_sync.grad_scale, db)                 # train.py:219
+    else:
+        hip_adam_step(optimizer_D)                                           # train.py:219
 
     return {"gen": gen.reshape(B, 1, H, W), "g_total": g_total, "g_loss": g_loss, "g_adv": g_adv, "d_loss": d_loss,
             "real_loss": real_loss, "fake_loss": fake_loss}

@@ -16,6 +16,7 @@ from torch.utils.data import DataLoader
 
 from tg_hip import engine as E
 from tg_hip import ops as O
+from tg_hip.gradbuf import grad_buffers
 
 from ..models._common import as_bhw, require_hip
 from ..train import _assign_grads, hip_adam_step
@@ -39,7 +40,7 @@ def human_guided_step(generator, criterion, optimizer, images, masks, human_mask
                                  accumulate=True, eps=criterion.boundary_loss.epsilon)
         total = O.lincomb(total, 1.0, out5[4:5], 1.0)
     optimizer.zero_grad()
-    grads, _ = E.generator_backward(GP, gctx, dgen)
+    grads, _ = E.generator_backward(GP, gctx, dgen, gbuf=grad_buffers(generator).views)
     _assign_grads(generator, grads)
     buckets = grad_sync(generator, "G") if grad_sync is not None else None
     hip_adam_step(optimizer, grad_sync.grad_scale if grad_sync is not None else 1.0, buckets)

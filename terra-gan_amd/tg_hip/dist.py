@@ -16,6 +16,8 @@ serialising the optimiser behind one 103 MB collective.
 import torch
 import torch.distributed as dist
 
+from .gradbuf import grad_buffers
+
 
 class Bucket:
     __slots__ = ("params", "flat", "work")
@@ -41,21 +43,20 @@ class GradSync:
         return 1.0 / self.world_size
 
     def _plan(self, module, tag):
+        gb = grad_buffers(module)                 # shared with the backward kernels: gradients are born in `flat`
         plan = self._plans.get(tag)
-        if plan is None:
-            params = [p for p in module.parameters() if p.requires_grad][::-1]
-            total = sum(p.numel() for p in params)
-            flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)
-            buckets, cur, start, off = [], [], 0, 0
-            for p in params:
+        if plan is None or plan[0] is not gb.flat:
+            buckets, cur, start, end = [], [], 0, 0
+            for k, p in gb.order:
+                off = gb.offsets[k]
                 cur.append((p, off))
-                off += p.numel()
-                if off - start >= self.bucket_elems:
-                    buckets.append((cur, start, off))
-                    cur, start = [], off
+                end = off + p.numel()
+                if end - start >= self.bucket_elems:
+                    buckets.append((cur, start, end))
+                    cur, start = [], (end + 63) // 64 * 64
             if cur:
-                buckets.append((cur, start, off))
-            plan = (flat, buckets)
+                buckets.append((cur, start, end))
+            plan = (gb.flat, buckets)
             self._plans[tag] = plan
         return plan
 
@@ -70,8 +71,9 @@ class GradSync:
                     raise RuntimeError("GradSync: a trainable parameter has no gradient")
                 # slice with the parameter's own physical layout (channels_last weights stay channels_last)
                 view = torch.as_strided(flat, p.shape, p.stride(), off) if _dense(p) else flat[off:off + p.numel()].view(p.shape)
-                view.copy_(p.grad)
-                p.grad = view
+                if p.grad.data_ptr() != view.data_ptr():      # gradient produced elsewhere (e.g. through autograd): pack it
+                    view.copy_(p.grad)
+                    p.grad = view
             b = Bucket([p for p, _ in plist], flat[start:end])
             if self.world_size > 1:
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

@@ -45,13 +45,16 @@ def _pconv_fwd(P, name, k, s, p, x, in_mask, ratio, training, premasked=False):
                  premasked=premasked)
 
 
-def _pconv_bwd(P, c, da, grads, dx_out=None, want_dx=True):
-    """da: grad w.r.t. the layer's ReLU output (consumed in place).  Returns dx (or None)."""
+def _pconv_bwd(P, c, da, grads, dx_out=None, want_dx=True, gbuf=None):
+    """da: grad w.r.t. the layer's ReLU output (consumed in place).  Returns dx (or None).
+    gbuf: {state-dict key: preallocated gradient tensor} (tg_hip.gradbuf) -- written in place when given."""
     name = c.name
+    outs = (gbuf[f"{name}.bn.weight"], gbuf[f"{name}.bn.bias"], gbuf[f"{name}.input_conv.bias"]) if gbuf is not None else None
     dyr, dgamma, dbeta, db = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU,
-                                          ratio=c.ratio)
+                                          ratio=c.ratio, outs=outs)
     dw, _ = O.conv_wgrad(c.x, dyr, P[f"{name}.input_conv.weight"], c.k, c.s, c.p,
-                         in_mask=None if getattr(c, "premasked", False) else c.in_mask, want_bias=False)
+                         in_mask=None if getattr(c, "premasked", False) else c.in_mask, want_bias=False,
+                         dw_out=gbuf[f"{name}.input_conv.weight"] if gbuf is not None else None)
     grads[f"{name}.input_conv.weight"], grads[f"{name}.input_conv.bias"] = dw, db
     grads[f"{name}.bn.weight"], grads[f"{name}.bn.bias"] = dgamma, dbeta
     if not want_dx:
@@ -98,18 +101,21 @@ def generator_forward(P, x, mask, training=True):
     return out, NS(enc=enc_ctx, dec=dec_ctx, d0=d, logits=logits, mask=mask, shape=(B, H, W))
 
 
-def generator_backward(P, ctx, dout, want_dx=False):
-    """dout: [B][H][W].  Returns (grads dict keyed like the state-dict, dx or None)."""
+def generator_backward(P, ctx, dout, want_dx=False, gbuf=None):
+    """dout: [B][H][W].  Returns (grads dict keyed like the state-dict, dx or None).  With `gbuf` (persistent gradient
+    views, tg_hip.gradbuf) the gradients are written there and the returned dict holds those same tensors."""
     B, H, W = ctx.shape
     grads = {}
     dz, dx_comp = O.sigmoid_composite_bwd(dout, ctx.logits.reshape(B, H, W), ctx.mask, want_dx)
     dz = dz.reshape(B, H, W, 1)
-    grads["final.weight"], grads["final.bias"] = O.conv_wgrad(ctx.d0, dz, P["final.weight"], 3, 1, 1)
+    grads["final.weight"], grads["final.bias"] = O.conv_wgrad(
+        ctx.d0, dz, P["final.weight"], 3, 1, 1, dw_out=gbuf["final.weight"] if gbuf is not None else None,
+        db_out=gbuf["final.bias"] if gbuf is not None else None)
     da = O.conv_dgrad(dz, P["final.weight"], tuple(ctx.d0.shape), 3, 1, 1)
     dskips = {}
     for i in range(6, -1, -1):                     # dec1 ... dec7
         c = ctx.dec[i]
-        dcat = _pconv_bwd(P, c, da, grads)
+        dcat = _pconv_bwd(P, c, da, grads, gbuf=gbuf)
         _b, h, w, Cu = c.up_shape
         da, dskip = O.upcat_bwd(dcat, h, w, Cu)
         if i < 6:
@@ -120,9 +126,9 @@ def generator_backward(P, ctx, dout, want_dx=False):
         c = ctx.enc[i]
         if i > 0:
             # gradient of e[i] = skip part (already there) + this layer's dgrad, accumulated in place
-            da = _pconv_bwd(P, c, da, grads, dx_out=dskips[i])
+            da = _pconv_bwd(P, c, da, grads, dx_out=dskips[i], gbuf=gbuf)
         else:
-            dx = _pconv_bwd(P, c, da, grads, want_dx=want_dx)
+            dx = _pconv_bwd(P, c, da, grads, want_dx=want_dx, gbuf=gbuf)
     if want_dx:
         dx = O.axpby_(dx_comp, 1.0, 1.0, dx.reshape(B, H, W))
     return grads, dx
@@ -154,7 +160,7 @@ def discriminator_forward(P, img, training=True):
     return h, NS(layers=layers)
 
 
-def discriminator_backward(P, ctx, dlogits, want_wgrad=True, want_dimg=False):
+def discriminator_backward(P, ctx, dlogits, want_wgrad=True, want_dimg=False, gbuf=None):
     """Returns (grads dict, dimg [B][H][W][C] or None).  want_wgrad=False skips the parameter
     gradients the reference computes and then discards in the generator step (train.py:204,210)."""
     grads, da, gated = {}, dlogits, False
@@ -166,12 +172,16 @@ def discriminator_backward(P, ctx, dlogits, want_wgrad=True, want_dimg=False):
             # the activation backward of a BN-less block is fused into the dgrad epilogue of the layer above it
             dy = da if (gated or c.act == O.ACT_NONE) else O.act_bwd(da, c.a, c.act, 0.2)
         else:
+            outs = (gbuf[f"model.{c.bi}.weight"], gbuf[f"model.{c.bi}.bias"], gbuf[f"model.{c.ci}.bias"]) \
+                if (gbuf is not None and want_wgrad) else None
             dy, dgamma, dbeta, db = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"model.{c.bi}.weight"], P[f"model.{c.bi}.bias"],
-                                                 O.ACT_LEAKY, 0.2, want_dbias=want_wgrad)
+                                                 O.ACT_LEAKY, 0.2, want_dbias=want_wgrad, outs=outs)
             if want_wgrad:
                 grads[f"model.{c.bi}.weight"], grads[f"model.{c.bi}.bias"] = dgamma, dbeta
         if want_wgrad:
-            dw, db2 = O.conv_wgrad(c.x, dy, w, c.k, c.s, c.p, want_bias=db is None)
+            dw, db2 = O.conv_wgrad(c.x, dy, w, c.k, c.s, c.p, want_bias=db is None,
+                                   dw_out=gbuf[f"model.{c.ci}.weight"] if gbuf is not None else None,
+                                   db_out=gbuf[f"model.{c.ci}.bias"] if (gbuf is not None and db is None) else None)
             grads[f"model.{c.ci}.weight"], grads[f"model.{c.ci}.bias"] = dw, (db if db is not None else db2)
         gated = False
         if li > 0 or want_dimg:

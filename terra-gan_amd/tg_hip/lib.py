@@ -54,6 +54,7 @@ SIGNATURES = {
     "tg_l1_mean": (I, [P, P, I64, F, P, P, P, P, SZ, P]),
     "tg_bce_logits": (I, [P, I64, F, F, P, P, P, P, SZ, P]),
     "tg_adam": (I, [P, P, P, P, I64, F, F, F, F, I, F, P]),
+    "tg_adam_multi": (I, [P, P, I, I, F, F, F, F, I, F, P]),
     "tg_axpby": (I, [P, F, F, P, I64, P]),
     "tg_lincomb": (I, [P, F, P, F, P, I64, P]),
     "tg_mul": (I, [P, P, P, I64, P]),

@@ -108,14 +108,19 @@ def conv_dgrad(dy, w, x_shape, k, stride, pad, in_mask=None, out=None, gate=None
     return dx
 
 
-def conv_wgrad(x, dy, w, k, stride, pad, in_mask=None, want_bias=True):
-    """Returns (dw, db): dw has the parameter's logical shape AND strides (channels_last)."""
+def conv_wgrad(x, dy, w, k, stride, pad, in_mask=None, want_bias=True, dw_out=None, db_out=None):
+    """Returns (dw, db): dw has the parameter's logical shape AND strides (channels_last).  dw_out / db_out:
+    preallocated destinations (persistent gradient buffers) with the parameter's layout."""
     _chk(x, "x"); _chk(dy, "dy"); _chk(in_mask, "in_mask")
     wv = weight_view(w)
     B, H, W, Cin = x.shape
     g = L.TgConv(B, H, W, Cin, dy.shape[1], dy.shape[2], dy.shape[3], k, stride, pad)
-    dwv = torch.empty_like(wv)                       # [Cout][k][k][Cin] contiguous
-    db = empty(g.Cout, like=x) if want_bias else None
+    if dw_out is not None:
+        dwv = dw_out.permute(0, 2, 3, 1)
+        assert dwv.is_contiguous() and dwv.shape == wv.shape
+    else:
+        dwv = torch.empty_like(wv)                   # [Cout][k][k][Cin] contiguous
+    db = (db_out if db_out is not None else empty(g.Cout, like=x)) if want_bias else None
     lib = _lib()
     ws = workspace(lib.tg_conv_wgrad_ws_bytes(C.byref(g)))
     L.check(lib.tg_conv_wgrad(C.byref(g), _p(x), _p(in_mask), _p(dy), _p(dwv), _p(db), _p(ws), ws.numel() * 4, _stream()),
@@ -185,15 +190,18 @@ def bn_act_fwd(y, mean, rstd, gamma, beta, act, slope=0.0):
     return out
 
 
-def bn_act_bwd(dout, y, mean, rstd, gamma, beta, act, slope=0.0, ratio=None, inplace=True, want_dbias=True):
+def bn_act_bwd(dout, y, mean, rstd, gamma, beta, act, slope=0.0, ratio=None, inplace=True, want_dbias=True, outs=None):
     """Returns (dy, dgamma, dbeta, dbias); dy overwrites dout when inplace.  dbias = sum_rows dy (the gradient of
     the bias of the conv feeding this BatchNorm), from the same reduction pass."""
     _chk(dout, "dout"); _chk(y, "y"); _chk(ratio, "ratio")
     Cc = y.shape[-1]
     rows = y.numel() // Cc
     dy = dout if inplace else torch.empty_like(dout)
-    dgamma, dbeta = empty(Cc, like=y), empty(Cc, like=y)
-    dbias = empty(Cc, like=y) if want_dbias else None
+    if outs is not None:                              # (dgamma, dbeta, dbias) persistent gradient buffers
+        dgamma, dbeta, dbias = outs
+    else:
+        dgamma, dbeta = empty(Cc, like=y), empty(Cc, like=y)
+        dbias = empty(Cc, like=y) if want_dbias else None
     lib = _lib()
     ws = workspace(lib.tg_bn_ws_bytes(rows, Cc))
     L.check(lib.tg_bn_act_bwd(_p(dout), _p(y), rows, Cc, _p(mean), _p(rstd), _p(gamma.detach()), _p(beta.detach()), act, slope,
@@ -315,6 +323,38 @@ def adam_(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
             raise L.TgError(f"adam_: {nm} layout {tuple(t.shape)}/{t.stride()} differs from the parameter's "
                             f"{tuple(p.shape)}/{p.stride()}")
     L.check(_lib().tg_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _stream()), "tg_adam")
+
+
+ADAM_CHUNK = 1 << 16
+_adam_tables = {}
+
+
+def adam_multi_(params, grads, ms, vs, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    """One-launch Adam over many tensors.  The (p, g, m, v, n) table and the work list live on the device and are
+    rebuilt only when a pointer changes (persistent gradient buffers keep them stable step after step)."""
+    import numpy as np
+    key = tuple(t.data_ptr() for ts in (params, grads, ms, vs) for t in ts)
+    ent = _adam_tables.get(key)
+    if ent is None:
+        lay = None
+        for p, g, m, v in zip(params, grads, ms, vs):
+            lay = _dense_layouts(p)
+            for t, nm in ((g, "g"), (m, "m"), (v, "v")):
+                if t.shape != p.shape or not (_dense_layouts(t) & lay):
+                    raise L.TgError(f"adam_multi_: {nm} layout differs from the parameter's ({tuple(p.shape)}/{p.stride()})")
+        seg = np.zeros((len(params), 5), dtype=np.int64)
+        work = []
+        for i, (p, g, m, v) in enumerate(zip(params, grads, ms, vs)):
+            seg[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+            work += [(i, c) for c in range((p.numel() + ADAM_CHUNK - 1) // ADAM_CHUNK)]
+        dev = params[0].device
+        ent = (torch.from_numpy(seg).to(dev), torch.tensor(work, dtype=torch.int32).to(dev), len(work))
+        if len(_adam_tables) > 64:
+            _adam_tables.clear()
+        _adam_tables[key] = ent
+    segs, work, nwork = ent
+    L.check(_lib().tg_adam_multi(C.c_void_p(segs.data_ptr()), C.c_void_p(work.data_ptr()), nwork, ADAM_CHUNK, lr, beta1, beta2,
+                                 eps, step, grad_scale, _stream()), "tg_adam_multi")
 
 
 def axpby_(x, a, b, y):

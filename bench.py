@@ -83,9 +83,15 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dp = os.environ.get("TG_FORCE_DP") == "1"        # exercise the RCCL path with a single rank (rehearsal)
+    if world > 1 or force_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        if force_dp and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
 
     from mvp_gan.src.models import Discriminator, PConvUNet
     from mvp_gan.src.train import train_step
@@ -102,7 +108,7 @@ def main():
     oG = torch.optim.Adam(G.parameters(), lr=2e-4)
     oD = torch.optim.Adam(D.parameters(), lr=2e-4)
     G.train(), D.train()
-    sync = GradSync(world) if world > 1 else None
+    sync = GradSync(world) if (world > 1 or force_dp) else None
 
     nb = 4                                                  # distinct resident batches, cycled
     batches = []
@@ -198,7 +204,7 @@ def main():
                            "vgg_weights": "deterministic stand-in (ImageNet weights not fetchable offline; same FLOPs)"},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

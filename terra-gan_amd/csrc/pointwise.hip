@@ -363,43 +363,64 @@ extern "C" int tg_bn_eval_stats(const float* running_mean, const float* running_
     return TG_OK;
 }
 
-// vectorised along channels when C % 4 == 0
-template <bool VEC>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, int64_t total, int C,
-                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         int act, float slope, float* __restrict__ out) {
-    if constexpr (VEC) {
-        const int64_t n4 = total / 4;
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-            const int c = (int)((i * 4) % C);
-            f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+// C % 4 == 0: a thread owns one channel quad (its per-channel constants live in registers) and walks rows, so the
+// inner loop is two 16-byte accesses and 4 FMAs -- no integer division.  qpp = min(C/4, 256) quads per pass.
+__global__ __launch_bounds__(256) void bn_act_fwd4_kernel(const float* __restrict__ y, int64_t rows, int C, int qpp, int rlanes,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          int act, float slope, float* __restrict__ out) {
+    const int cq = threadIdx.x % qpp, rl = threadIdx.x / qpp;
+    if (rl >= rlanes) return;
+    const int nquads = C >> 2;
+    for (int q0 = blockIdx.y * qpp; q0 < nquads; q0 += gridDim.y * qpp) {
+        const int c0 = (q0 + cq) * 4;
+        if (c0 >= C) continue;
+        const f32x4 mv = *reinterpret_cast<const f32x4*>(mean + c0), rv = *reinterpret_cast<const f32x4*>(rstd + c0);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + c0), bv = *reinterpret_cast<const f32x4*>(beta + c0);
+        for (int64_t r = (int64_t)blockIdx.x * rlanes + rl; r < rows; r += (int64_t)gridDim.x * rlanes) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * C + c0);
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float xh = (v[e] - mean[c + e]) * rstd[c + e];
-                o[e] = apply_act(xh * gamma[c + e] + beta[c + e], act, slope);
-            }
-            reinterpret_cast<f32x4*>(out)[i] = o;
-        }
-    } else {
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-            const int c = (int)(i % C);
-            float xh = (y[i] - mean[c]) * rstd[c];
-            out[i] = apply_act(xh * gamma[c] + beta[c], act, slope);
+            for (int e = 0; e < 4; ++e) o[e] = apply_act((v[e] - mv[e]) * rv[e] * gv[e] + bv[e], act, slope);
+            *reinterpret_cast<f32x4*>(out + r * C + c0) = o;
         }
     }
+}
+__global__ __launch_bounds__(256) void bn_act_fwd1_kernel(const float* __restrict__ y, int64_t total, int C,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          int act, float slope, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        float xh = (y[i] - mean[c]) * rstd[c];
+        out[i] = apply_act(xh * gamma[c] + beta[c], act, slope);
+    }
+}
+struct RowGeom {
+    int qpp, rlanes;
+    dim3 grid;
+};
+static RowGeom row_geom(int64_t rows, int C) {
+    RowGeom g;
+    const int nquads = C / 4;
+    g.qpp = nquads < 256 ? nquads : 256;
+    g.rlanes = 256 / g.qpp;
+    int64_t gx = cdiv64(rows, (int64_t)g.rlanes * 4);
+    if (gx > 2048) gx = 2048;
+    if (gx < 1) gx = 1;
+    g.grid = dim3((unsigned)gx, (unsigned)cdiv(nquads, g.qpp));
+    return g;
 }
 extern "C" int tg_bn_act_fwd(const float* y, int64_t rows, int C, const float* mean, const float* rstd, const float* gamma,
                              const float* beta, int act, float slope, float* out, tg_stream_t stream) {
     TG_REQUIRE(y && mean && rstd && gamma && beta && out && rows > 0 && C > 0, "tg_bn_act_fwd: bad arguments");
-    const int64_t total = rows * C;
     if (C % 4 == 0) {
-        hipLaunchKernelGGL((bn_act_fwd_kernel<true>), dim3(ew_grid(total / 4, 256)), dim3(256), 0, S(stream), y, total, C, mean,
-                           rstd, gamma, beta, act, slope, out);
+        RowGeom g = row_geom(rows, C);
+        hipLaunchKernelGGL(bn_act_fwd4_kernel, g.grid, dim3(256), 0, S(stream), y, rows, C, g.qpp, g.rlanes, mean, rstd, gamma,
+                           beta, act, slope, out);
     } else {
-        hipLaunchKernelGGL((bn_act_fwd_kernel<false>), dim3(ew_grid(total, 256)), dim3(256), 0, S(stream), y, total, C, mean,
-                           rstd, gamma, beta, act, slope, out);
+        hipLaunchKernelGGL(bn_act_fwd1_kernel, dim3(ew_grid(rows * C, 256)), dim3(256), 0, S(stream), y, rows * C, C, mean, rstd,
+                           gamma, beta, act, slope, out);
     }
     TG_CHECK_LAUNCH("bn_act_fwd_kernel");
     return TG_OK;
@@ -460,32 +481,46 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
     // dy = gamma*rstd*(g - dbeta/n - xhat*dgamma/n)  =>  sum_rows ratio*dy
     if (dbias) dbias[c] = (float)((double)gamma[c] * (double)rstd[c] * (q[2] - q[0] / n * q[4] - q[1] / n * q[3]));
 }
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
-                                                           int64_t rows, int C, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, int act, float slope,
-                                                           const float* __restrict__ ratio, const float* __restrict__ dgamma,
-                                                           const float* __restrict__ dbeta, float* __restrict__ dy) {
-    const int64_t total = rows * C;
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                            int64_t rows, int C, int qpp, int rlanes,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int act, float slope, const float* __restrict__ ratio,
+                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                            float* __restrict__ dy) {
+    const int cq = threadIdx.x % qpp, rl = threadIdx.x / qpp;
+    if (rl >= rlanes) return;
     const float inv_n = 1.0f / (float)rows;
-    if ((C & 3) == 0) {
-        const int64_t n4 = total >> 2;
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-            const int c = (int)((i * 4) % C);
-            const int64_t r = (i * 4) / C;
-            const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i], dv = reinterpret_cast<const f32x4*>(dout)[i];
+    const int nquads = C >> 2;
+    for (int q0 = blockIdx.y * qpp; q0 < nquads; q0 += gridDim.y * qpp) {
+        const int c0 = (q0 + cq) * 4;
+        if (c0 >= C) continue;
+        const f32x4 mv = *reinterpret_cast<const f32x4*>(mean + c0), rv = *reinterpret_cast<const f32x4*>(rstd + c0);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + c0), bv = *reinterpret_cast<const f32x4*>(beta + c0);
+        const f32x4 dgv = *reinterpret_cast<const f32x4*>(dgamma + c0), dbv = *reinterpret_cast<const f32x4*>(dbeta + c0);
+        for (int64_t r = (int64_t)blockIdx.x * rlanes + rl; r < rows; r += (int64_t)gridDim.x * rlanes) {
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * C + c0);
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(dout + r * C + c0);
             const float rr = ratio ? ratio[r] : 1.f;
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float xh = (yv[e] - mean[c + e]) * rstd[c + e];
-                float g = dv[e] * act_grad(xh * gamma[c + e] + beta[c + e], act, slope);
-                o[e] = gamma[c + e] * rstd[c + e] * (g - dbeta[c + e] * inv_n - xh * dgamma[c + e] * inv_n) * rr;
+                float xh = (yv[e] - mv[e]) * rv[e];
+                float g = dv[e] * act_grad(xh * gv[e] + bv[e], act, slope);
+                o[e] = gv[e] * rv[e] * (g - dbv[e] * inv_n - xh * dgv[e] * inv_n) * rr;
             }
-            reinterpret_cast<f32x4*>(dy)[i] = o;
+            *reinterpret_cast<f32x4*>(dy + r * C + c0) = o;
         }
-        return;
     }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply1_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                            int64_t rows, int C, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int act, float slope,
+                                                            const float* __restrict__ ratio, const float* __restrict__ dgamma,
+                                                            const float* __restrict__ dbeta, float* __restrict__ dy) {
+    const int64_t total = rows * C;
+    const float inv_n = 1.0f / (float)rows;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const int64_t r = i / C;
@@ -519,8 +554,14 @@ extern "C" int tg_bn_act_bwd(const float* dout, const float* y, int64_t rows, in
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fr_grid(C)), dim3(256), 0, S(stream), ws, nblocks, C, (double)rows, gamma, rstd,
                        dgamma, dbeta, dbias);
     TG_CHECK_LAUNCH("bn_bwd_final");
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((C % 4) ? rows * C : rows * C / 4, 256)), dim3(256), 0, S(stream), dout, y, rows, C, mean,
-                       rstd, gamma, beta, act, slope, ratio, dgamma, dbeta, dy);
+    if (C % 4 == 0) {
+        RowGeom rg = row_geom(rows, C);
+        hipLaunchKernelGGL(bn_bwd_apply4_kernel, rg.grid, dim3(256), 0, S(stream), dout, y, rows, C, rg.qpp, rg.rlanes, mean, rstd,
+                           gamma, beta, act, slope, ratio, dgamma, dbeta, dy);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_apply1_kernel, dim3(ew_grid(rows * C, 256)), dim3(256), 0, S(stream), dout, y, rows, C, mean,
+                           rstd, gamma, beta, act, slope, ratio, dgamma, dbeta, dy);
+    }
     TG_CHECK_LAUNCH("bn_bwd_apply");
     return TG_OK;
 }
@@ -780,22 +821,51 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
         const int64_t base = (((int64_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
         const bool full = oy < Ho && ox < Wo;
         const bool has_r = 2 * ox + 1 < W, has_d = 2 * oy + 1 < H;
+        float xv[4][V], gv[4][V], dv[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            float g[4] = {0.f, 0.f, 0.f, 0.f};
-            if (full) {
-                const float v[4] = {x[base + e], x[base + C + e], x[base + (int64_t)W * C + e], x[base + (int64_t)W * C + C + e]};
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < V; ++e) { xv[k][e] = 0.f; gv[k][e] = 0.f; }
+        if (full) {
+            const int64_t offs[4] = {0, C, (int64_t)W * C, (int64_t)W * C + C};
+            if constexpr (V == 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(x + base + offs[k]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[k][e] = t4[e];
+                }
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dout + (((int64_t)b * Ho + oy) * Wo + ox) * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dv[e] = d4[e];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xv[k][0] = x[base + offs[k]];
+                dv[0] = dout[(((int64_t)b * Ho + oy) * Wo + ox) * C + c];
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
                 int am = 0;
-                float best = v[0];
+                float best = xv[0][e];
 #pragma unroll
                 for (int k = 1; k < 4; ++k)
-                    if (v[k] > best) { best = v[k]; am = k; }
-                if (!(relu_gate && best <= 0.f)) g[am] = dout[(((int64_t)b * Ho + oy) * Wo + ox) * C + c + e];
+                    if (xv[k][e] > best) { best = xv[k][e]; am = k; }
+                const float gval = (relu_gate && best <= 0.f) ? 0.f : dv[e];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gv[k][e] = (k == am) ? gval : 0.f;
             }
-            dx[base + e] = g[0];
-            if (has_r) dx[base + C + e] = g[1];
-            if (has_d) dx[base + (int64_t)W * C + e] = g[2];
-            if (has_r && has_d) dx[base + (int64_t)W * C + C + e] = g[3];
+        }
+        const int64_t offs2[4] = {0, C, (int64_t)W * C, (int64_t)W * C + C};
+        const bool wr[4] = {true, has_r, has_d, has_r && has_d};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!wr[k]) continue;
+            if constexpr (V == 4) {
+                f32x4 o = {gv[k][0], gv[k][1], gv[k][2], gv[k][3]};
+                *reinterpret_cast<f32x4*>(dx + base + offs2[k]) = o;
+            } else {
+                dx[base + offs2[k]] = gv[k][0];
+            }
         }
     }
 }
@@ -1063,7 +1133,28 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const TgAdamSeg* __rest
     const TgAdamSeg sg = segs[seg];
     const int64_t begin = (int64_t)chunk * chunk_elems;
     const int64_t end = min(sg.n, begin + chunk_elems);
-    for (int64_t i = begin + threadIdx.x; i < end; i += 256) {
+    const bool al = ((reinterpret_cast<uintptr_t>(sg.p) | reinterpret_cast<uintptr_t>(sg.g) | reinterpret_cast<uintptr_t>(sg.m) |
+                      reinterpret_cast<uintptr_t>(sg.v)) & 15) == 0;
+    int64_t i = begin;
+    if (al) {       // chunk_elems is a multiple of 4: 16-byte accesses over the aligned body
+        const int64_t end4 = begin + ((end - begin) & ~(int64_t)3);
+        for (i = begin + 4 * threadIdx.x; i < end4; i += 4 * 256) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(sg.g + i);
+            f32x4 m4 = *reinterpret_cast<f32x4*>(sg.m + i), v4 = *reinterpret_cast<f32x4*>(sg.v + i), p4 = *reinterpret_cast<f32x4*>(sg.p + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gr = g4[e] * grad_scale;
+                m4[e] = m4[e] + one_minus_b1 * (gr - m4[e]);
+                v4[e] = v4[e] * b2 + one_minus_b2 * gr * gr;
+                p4[e] = p4[e] - step_size * (m4[e] / (sqrtf(v4[e]) * inv_bc2_sqrt + eps));
+            }
+            *reinterpret_cast<f32x4*>(sg.m + i) = m4;
+            *reinterpret_cast<f32x4*>(sg.v + i) = v4;
+            *reinterpret_cast<f32x4*>(sg.p + i) = p4;
+        }
+        i = end4;
+    }
+    for (i += threadIdx.x; i < end; i += 256) {
         const float gr = sg.g[i] * grad_scale;
         const float mi = sg.m[i] + one_minus_b1 * (gr - sg.m[i]);
         const float vi = sg.v[i] * b2 + one_minus_b2 * gr * gr;

@@ -325,7 +325,7 @@ def adam_(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     L.check(_lib().tg_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _stream()), "tg_adam")
 
 
-ADAM_CHUNK = 1 << 16
+ADAM_CHUNK = 1 << 14
 _adam_tables = {}
 
 

@@ -81,6 +81,11 @@ def main():
         print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    # rehearsal switches (never used by the driver): all ranks on device 0 + gloo transport, to exercise the
+    # multi-rank control flow on a single-GPU box
+    backend = os.environ.get("TG_DIST_BACKEND", "nccl")
+    if os.environ.get("TG_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force_dp = os.environ.get("TG_FORCE_DP") == "1"        # exercise the RCCL path with a single rank (rehearsal)
@@ -91,7 +96,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29531")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         else:
-            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+            else:
+                dist.init_process_group(backend)
 
     from mvp_gan.src.models import Discriminator, PConvUNet
     from mvp_gan.src.train import train_step
@@ -134,20 +142,23 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
-        # instrumented pass (outside the timed region): hipEvents around every MFMA conv launch, on its launch stream
+    if not args.no_roofline:
+        # instrumented pass (outside the timed region): hipEvents around every MFMA conv launch, on its launch stream.
+        # Every rank runs the probe steps (they contain the gradient all-reduce); only rank 0 records.
         import csv
         import tempfile
         nprobe = 2
-        lib.tg_prof_enable(1)
+        if rank == 0:
+            lib.tg_prof_enable(1)
         run(nprobe)
         torch.cuda.synchronize()
         lib.tg_prof_enable(0)
+    if rank == 0 and not args.no_roofline:
         dump = args.prof_dump or os.path.join(tempfile.gettempdir(), f"tg_prof_{os.getpid()}.csv")
         lib.tg_prof_dump(dump.encode())
         rows = list(csv.DictReader(open(dump)))

@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--size", type=int, default=TILE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--checkpoint", action="store_true", help="activation checkpointing in the generator (config 5)")
     ap.add_argument("--prof-dump", default=None, help="write the per-launch table of the instrumented pass to this CSV")
     args = ap.parse_args()
 
@@ -116,6 +117,7 @@ def main():
     oG = torch.optim.Adam(G.parameters(), lr=2e-4)
     oD = torch.optim.Adam(D.parameters(), lr=2e-4)
     G.train(), D.train()
+    G.activation_checkpointing = args.checkpoint
     sync = GradSync(world) if (world > 1 or force_dp) else None
 
     nb = 4                                                  # distinct resident batches, cycled

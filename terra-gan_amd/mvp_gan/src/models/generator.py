@@ -42,6 +42,9 @@ class PConvUNet(TensorDictMixin, nn.Module):
             setattr(self, name, PConv2d(cin, cout, kernel_size=k, stride=s, padding=p))
         self.final = nn.Conv2d(64, 1, kernel_size=3, padding=1)
         to_channels_last_(self.final)
+        # train_step(): drop post-activation / concat tensors after forward and recompute them in backward
+        # (BASELINE config 5).  Off by default: 288 GB of HBM hold 1024x1024 tiles at batch 4 without it.
+        self.activation_checkpointing = False
 
     def forward(self, x, mask):
         require_hip(x, "PConvUNet")

@@ -109,7 +109,8 @@ def train_step(generator, discriminator, criterion, optimizer_G, optimizer_D, re
 
     # ---- generator ------------------------------------------------------------------------------
     optimizer_G.zero_grad()                                                  # set_to_none (App. A #12)
-    gen, gctx = E.generator_forward(GP, masked, mask, generator.training)    # train.py:185
+    gen, gctx = E.generator_forward(GP, masked, mask, generator.training,
+                                    checkpoint=getattr(generator, "activation_checkpointing", False))     # train.py:185
     g_loss, _parts, dgen = criterion_forward(criterion, gen, real, mask, want_grad=True)   # train.py:188
     fake_logits, dctx_fake = E.discriminator_forward(DP, gen, discriminator.training)      # train.py:202
     g_adv, dlogits = O.bce_logits(fake_logits, 1.0)                          # train.py:203

@@ -65,8 +65,12 @@ def _pconv_bwd(P, c, da, grads, dx_out=None, want_dx=True, gbuf=None):
 # --------------------------------------------------------------------------------------------------
 # generator
 # --------------------------------------------------------------------------------------------------
-def generator_forward(P, x, mask, training=True):
-    """x (already masked image) and mask: [B][H][W].  Returns (out [B][H][W], ctx)."""
+def generator_forward(P, x, mask, training=True, checkpoint=False):
+    """x (already masked image) and mask: [B][H][W].  Returns (out [B][H][W], ctx).
+    checkpoint=True (activation checkpointing, BASELINE config 5): only the pre-BatchNorm conv outputs, the batch
+    statistics and the (1-channel) masks are kept; the post-activation tensors and the decoder concat tensors --
+    more than half of the footprint -- are dropped and recomputed in backward (one BN+ReLU pass and one
+    upsample/concat pass per layer, ~3 % of a step)."""
     B, H, W = x.shape
     # mask pyramid first: it depends on the input mask only (pconv.py:33-40, generator.py:51-54,68,74)
     m, er = [mask], [None]
@@ -94,11 +98,23 @@ def generator_forward(P, x, mask, training=True):
         up_shape = tuple(d.shape)
         cat = O.upcat_fwd(d, skip, Hs, Ws, out_mask=dmasks[i])       # = merged_feature * merged_mask
         d, c = _pconv_fwd(P, name, k, s, p, cat, dmasks[i], dr[i], training, premasked=True)
-        c.up_shape = up_shape
+        c.up_shape, c.x_shape, c.skip_hw = up_shape, tuple(cat.shape), (Hs, Ws)
+        if checkpoint:
+            c.x = None                                               # concat tensor: rebuilt in backward
         dec_ctx.append(c)
     logits = O.conv_fwd(d, P["final.weight"], P["final.bias"].detach(), 3, 1, 1)      # generator.py:29,56
     out = O.sigmoid_composite_fwd(logits.reshape(B, H, W), x, mask)                     # generator.py:57-62
-    return out, NS(enc=enc_ctx, dec=dec_ctx, d0=d, logits=logits, mask=mask, shape=(B, H, W))
+    if checkpoint:
+        for i in range(1, 7):
+            enc_ctx[i].x_shape = tuple(enc_ctx[i].x.shape)
+            enc_ctx[i].x = None                                      # = ReLU(BN(y)) of the previous encoder layer
+        d = None
+    return out, NS(enc=enc_ctx, dec=dec_ctx, d0=d, logits=logits, mask=mask, shape=(B, H, W), checkpoint=checkpoint)
+
+
+def _act_of(P, c):
+    """Recompute a layer's ReLU(BN(y)) from its kept pre-BN output and batch statistics."""
+    return O.bn_act_fwd(c.y, c.mean, c.rstd, P[f"{c.name}.bn.weight"], P[f"{c.name}.bn.bias"], O.ACT_RELU)
 
 
 def generator_backward(P, ctx, dout, want_dx=False, gbuf=None):
@@ -106,16 +122,26 @@ def generator_backward(P, ctx, dout, want_dx=False, gbuf=None):
     views, tg_hip.gradbuf) the gradients are written there and the returned dict holds those same tensors."""
     B, H, W = ctx.shape
     grads = {}
+    ckpt = getattr(ctx, "checkpoint", False)
     dz, dx_comp = O.sigmoid_composite_bwd(dout, ctx.logits.reshape(B, H, W), ctx.mask, want_dx)
     dz = dz.reshape(B, H, W, 1)
+    d0 = _act_of(P, ctx.dec[6]) if ckpt else ctx.d0
     grads["final.weight"], grads["final.bias"] = O.conv_wgrad(
-        ctx.d0, dz, P["final.weight"], 3, 1, 1, dw_out=gbuf["final.weight"] if gbuf is not None else None,
+        d0, dz, P["final.weight"], 3, 1, 1, dw_out=gbuf["final.weight"] if gbuf is not None else None,
         db_out=gbuf["final.bias"] if gbuf is not None else None)
-    da = O.conv_dgrad(dz, P["final.weight"], tuple(ctx.d0.shape), 3, 1, 1)
+    da = O.conv_dgrad(dz, P["final.weight"], tuple(d0.shape), 3, 1, 1)
+    del d0
     dskips = {}
     for i in range(6, -1, -1):                     # dec1 ... dec7
         c = ctx.dec[i]
+        if ckpt:                                   # rebuild this layer's (pre-masked) concat input
+            up_src = _act_of(P, ctx.dec[i - 1]) if i > 0 else _act_of(P, ctx.enc[6])
+            skip = _act_of(P, ctx.enc[5 - i]) if i < 6 else None
+            c.x = O.upcat_fwd(up_src, skip, c.skip_hw[0], c.skip_hw[1], out_mask=c.in_mask)
+            del up_src, skip
         dcat = _pconv_bwd(P, c, da, grads, gbuf=gbuf)
+        if ckpt:
+            c.x = None
         _b, h, w, Cu = c.up_shape
         da, dskip = O.upcat_bwd(dcat, h, w, Cu)
         if i < 6:
@@ -124,9 +150,13 @@ def generator_backward(P, ctx, dout, want_dx=False, gbuf=None):
     dx = None
     for i in range(6, -1, -1):                     # enc7 ... enc1
         c = ctx.enc[i]
+        if ckpt and i > 0:
+            c.x = _act_of(P, ctx.enc[i - 1])
         if i > 0:
             # gradient of e[i] = skip part (already there) + this layer's dgrad, accumulated in place
             da = _pconv_bwd(P, c, da, grads, dx_out=dskips[i], gbuf=gbuf)
+            if ckpt:
+                c.x = None
         else:
             dx = _pconv_bwd(P, c, da, grads, want_dx=want_dx, gbuf=gbuf)
     if want_dx:

@@ -225,3 +225,21 @@ def test_dp2_train_step_golden(dev):
         ref = gold[f"dp2_128/w/{name}"]
         per = lr if (name.endswith("input_conv.bias") or name in ("D.model.2.bias", "D.model.5.bias", "D.model.8.bias")) else 2e-2 * lr
         assert abs(sm - ref[0]) <= per * n + 6 * lr + 1e-6 * abs(ref[1]), (name, sm, ref[0])
+
+
+def test_activation_checkpointing_is_exact(dev):
+    """Config 5's activation checkpointing only changes WHEN tensors exist, never their values."""
+    from mvp_gan.src.train import train_step
+    from oracle import terragan_oracle as Orc
+    real, mask = Orc.synth_batch(2, 128, 77)
+    real, mask = real.to(dev), mask.to(dev)
+    res = []
+    for ck in (False, True):
+        G, D, crit, oG, oD = _build(dev)
+        G.activation_checkpointing = ck
+        torch.cuda.reset_peak_memory_stats()
+        out = train_step(G, D, crit, oG, oD, real, mask)
+        res.append(([p_.detach().clone() for p_ in G.parameters()], float(out["g_total"]), torch.cuda.max_memory_allocated()))
+    assert res[0][1] == res[1][1]
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)

@@ -592,9 +592,7 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
                 const bool next_chunk = last_tap && (c + 1 < c_end);
                 const bool more = !last_tap || next_chunk;
                 if (more) wload(last_tap ? c + 1 : c, last_tap ? 0 : tap + 1);
-                if constexpr (PREFETCH) {
-                    if (next_chunk) pload(c + 1, 0);
-                }
+                if (next_chunk) pload(c + 1, 0);      // first register batch of the next patch rides under this tap's MFMAs
                 const int ty = tap / g.TW, tx = tap - ty * g.TW;
                 const int toff = ((g.sy0 + ty * p.tstep - g.sy_min) * g.PW + (g.sx0 + tx * p.tstep - g.sx_min)) * LDK;
                 const float* Bb = Bs + cur * BN * LDK;
@@ -625,14 +623,11 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
                 }
                 if (next_chunk) {
                     __syncthreads();        // every wave is done with the current patch
-                    if constexpr (PREFETCH) {
-                        pstore(0);
-                    } else {
+                    pstore(0);
 #pragma unroll
-                        for (int bt = 0; bt < NBATCH; ++bt) {
-                            pload(c + 1, bt);
-                            pstore(bt);
-                        }
+                    for (int bt = 1; bt < NBATCH; ++bt) {     // 16x16 tile: second batch behind the barrier
+                        pload(c + 1, bt);
+                        pstore(bt);
                     }
                 }
                 if (more) wstore(cur ^ 1);

@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--size", type=int, default=TILE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+                    help="conv inner-product arithmetic: f32 (BASELINE config 2, default) or bf16 operands + fp32 accumulate (config 3)")
     ap.add_argument("--checkpoint", action="store_true", help="activation checkpointing in the generator (config 5)")
     ap.add_argument("--prof-dump", default=None, help="write the per-launch table of the instrumented pass to this CSV")
     args = ap.parse_args()
@@ -109,6 +111,8 @@ def main():
     from tg_hip import lib as L
     from tg_hip.dist import GradSync
     lib = L.load()
+    from tg_hip import ops as _O
+    _O.set_precision(args.precision)
 
     torch.manual_seed(0)                                    # identical weights on every rank
     G, D = PConvUNet(), Discriminator()
@@ -164,7 +168,7 @@ def main():
         dump = args.prof_dump or os.path.join(tempfile.gettempdir(), f"tg_prof_{os.getpid()}.csv")
         lib.tg_prof_dump(dump.encode())
         rows = list(csv.DictReader(open(dump)))
-        for kind in (0, 1, 2):
+        for kind in (0, 1, 2, 3):
             prof_summary(lib, kind)                       # consume the records
 
         def agg(pred):
@@ -191,7 +195,8 @@ def main():
         for name, pred in [("all_conv_fwd_dgrad_mfma", lambda r: r["kind"] == "0"),
                            ("pgemm_256x64_tile", lambda r: r["kind"] == "0" and r["cfg"] == "1064"),
                            ("wgrad_mfma", lambda r: r["kind"] == "1"),
-                           ("one_channel_convs_hbm", lambda r: r["kind"] == "2")]:
+                           ("one_channel_convs_hbm", lambda r: r["kind"] == "2"),
+                           ("pgemm_bf16_operands", lambda r: r["kind"] == "3")]:
             ms_, n_, fl_, by_ = agg(pred)
             if ms_ > 0:
                 extra[name] = {"kernel_ms_per_step": round(ms_ / nprobe, 3), "launches_per_step": n_ // nprobe,
@@ -209,7 +214,7 @@ def main():
         line = {"metric": "DSM tiles/sec train-step (G+D) at 256x256 bs=16", "value": round(tiles / elapsed, 2),
                 "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16 operands / f32 accumulate+storage", "data": "synthetic",
                 "config": {"workload": f"BASELINE configs[1]: {args.size}x{args.size} 1-ch DSM tiles, batch {args.batch} per GPU, "
                                        "fp32, PConv-UNet G + PatchGAN D + L1/VGG-perceptual/TV/boundary losses + 2x Adam",
                            "global_batch": args.batch * world, "tile": args.size,

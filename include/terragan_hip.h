@@ -32,12 +32,17 @@ typedef void* tg_stream_t; /* hipStream_t */
 
 enum { TG_OK = 0, TG_ERR_ARG = -1, TG_ERR_LAUNCH = -2, TG_ERR_WS = -3 };
 enum { TG_ACT_NONE = 0, TG_ACT_RELU = 1, TG_ACT_LEAKY = 2 };
+/* Arithmetic of the conv inner product.  TG_PREC_BF16: operands are rounded to bf16 inside the kernel and multiplied
+ * on the bf16 MFMA with fp32 accumulation; tensors in memory, bias, mask ratio and epilogue stay fp32
+ * (BASELINE config 3: bf16 compute, fp32 master weights).  Kernels without a bf16 variant ignore it. */
+enum { TG_PREC_F32 = 0, TG_PREC_BF16 = 1 };
 
 /* Geometry of one 2-D convolution (square kernel, symmetric padding). */
 typedef struct TgConv {
     int32_t B, H, W, Cin;   /* input  [B][H][W][Cin]   */
     int32_t Ho, Wo, Cout;   /* output [B][Ho][Wo][Cout] */
     int32_t k, stride, pad;
+    int32_t precision;      /* TG_PREC_* */
 } TgConv;
 
 int tg_version(void);

@@ -457,14 +457,20 @@ struct PatchGeom {
     ClassGeom c[4];
 };
 
-template <int TH_, int TW_, int WAVES_M, int WAVES_N, int WM, int WN, int MAXPL>
+// BF16 = true: operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when they are staged into LDS and multiplied on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (16x the fp32 MFMA rate); activations, weights, masks, bias and
+// the whole epilogue stay fp32 (BASELINE config 3: bf16 compute, fp32 masters).  LDS rows are 32 bf16 + 8 pad (80 B):
+// the 16-byte fragment fetch (8 consecutive k per lane) is bank-conflict free.
+template <int TH_, int TW_, int WAVES_M, int WAVES_N, int WM, int WN, int MAXPL, bool BF16>
 __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, const PatchGeom q) {
-    constexpr int BM = TH_ * TW_, BN = WAVES_N * WN * 32, LDK = 36;
+    constexpr int BM = TH_ * TW_, BN = WAVES_N * WN * 32, LDK = 36, LDH = 40;
     constexpr int B_LOADS = BN / 32;
     static_assert(BM == WAVES_M * WM * 32 && WAVES_M * WAVES_N == 4, "tile/wave mismatch");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bs = smem;                    // [2][BN][LDK]
     float* Ps = smem + 2 * BN * LDK;     // [PH*PW][LDK]
+    __bf16* Bh = reinterpret_cast<__bf16*>(smem);     // bf16 images: [2][BN][LDH] then [PH*PW][LDH]
+    __bf16* Ph = Bh + 2 * BN * LDH;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -518,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int r = (wm * WM + i) * 32 + (lane & 31);
-        abase[i] = ((r / TW_) * p.ss * g.PW + (r % TW_) * p.ss) * LDK + 4 * (lane >> 5);
+        abase[i] = ((r / TW_) * p.ss * g.PW + (r % TW_) * p.ss) * (BF16 ? LDH : LDK) + (BF16 ? 8 : 4) * (lane >> 5);
     }
     const int brow = wn * WN * 32 + (lane & 31);
     const int ko = 4 * (lane >> 5);
@@ -547,7 +553,10 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
         for (int i = 0; i < PB; ++i) {
             const int sl = batch * PB + i;
             const int idx = tid + 256 * sl;
-            if (sl < MAXPL && (idx >> 3) < ppix) *reinterpret_cast<f32x4*>(Ps + (idx >> 3) * LDK + 4 * kc) = rp[i];
+            if (sl < MAXPL && (idx >> 3) < ppix) {
+                if constexpr (BF16) *reinterpret_cast<bf16x4*>(Ph + (idx >> 3) * LDH + 4 * kc) = __builtin_convertvector(rp[i], bf16x4);
+                else *reinterpret_cast<f32x4*>(Ps + (idx >> 3) * LDK + 4 * kc) = rp[i];
+            }
         }
     };
     constexpr int NBATCH = PREFETCH ? 1 : 2;
@@ -563,9 +572,16 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
         }
     };
     auto wstore = [&](int buf) {
-        float* Bb = Bs + buf * BN * LDK;
+        if constexpr (BF16) {
+            __bf16* Bb = Bh + buf * BN * LDH;
 #pragma unroll
-        for (int j = 0; j < B_LOADS; ++j) *reinterpret_cast<f32x4*>(Bb + (r0 + 32 * j) * LDK + 4 * kc) = rw[j];
+            for (int j = 0; j < B_LOADS; ++j)
+                *reinterpret_cast<bf16x4*>(Bb + (r0 + 32 * j) * LDH + 4 * kc) = __builtin_convertvector(rw[j], bf16x4);
+        } else {
+            float* Bb = Bs + buf * BN * LDK;
+#pragma unroll
+            for (int j = 0; j < B_LOADS; ++j) *reinterpret_cast<f32x4*>(Bb + (r0 + 32 * j) * LDK + 4 * kc) = rw[j];
+        }
     };
 
     f32x16 acc[WM][WN];
@@ -594,7 +610,27 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
                 if (more) wload(last_tap ? c + 1 : c, last_tap ? 0 : tap + 1);
                 if (next_chunk) pload(c + 1, 0);      // first register batch of the next patch rides under this tap's MFMAs
                 const int ty = tap / g.TW, tx = tap - ty * g.TW;
-                const int toff = ((g.sy0 + ty * p.tstep - g.sy_min) * g.PW + (g.sx0 + tx * p.tstep - g.sx_min)) * LDK;
+                const int toff = ((g.sy0 + ty * p.tstep - g.sy_min) * g.PW + (g.sx0 + tx * p.tstep - g.sx_min)) * (BF16 ? LDH : LDK);
+                if constexpr (BF16) {
+                    const __bf16* Bb = Bh + cur * BN * LDH;
+                    const int kh8 = 8 * (lane >> 5);
+                    bf16x8 ah[2][WM], bh[2][WN];
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) ah[0][i] = *reinterpret_cast<const bf16x8*>(Ph + abase[i] + toff);
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) bh[0][j] = *reinterpret_cast<const bf16x8*>(Bb + (brow + 32 * j) * LDH + kh8);
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) ah[1][i] = *reinterpret_cast<const bf16x8*>(Ph + abase[i] + toff + 16);
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) bh[1][j] = *reinterpret_cast<const bf16x8*>(Bb + (brow + 32 * j) * LDH + 16 + kh8);
+#pragma unroll
+                    for (int gk = 0; gk < 2; ++gk)
+#pragma unroll
+                        for (int i = 0; i < WM; ++i)
+#pragma unroll
+                            for (int j = 0; j < WN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[gk][i], bh[gk][j], acc[i][j], 0, 0, 0);
+                } else {
                 const float* Bb = Bs + cur * BN * LDK;
                 f32x4 a[2][WM], bb[2][WN];       // register double-buffered fragments (see igemm_kernel)
 #pragma unroll
@@ -620,6 +656,7 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
                             for (int j = 0; j < WN; ++j)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg & 1][i][e], bb[kg & 1][j][e], acc[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
+                }
                 }
                 if (next_chunk) {
                     __syncthreads();        // every wave is done with the current patch
@@ -673,14 +710,14 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
     }
 }
 
-template <int TH_, int TW_, int WAVES_M, int WAVES_N, int WM, int WN, int MAXPL>
+template <int TH_, int TW_, int WAVES_M, int WAVES_N, int WM, int WN, int MAXPL, bool BF16>
 static int launch_pgemm_cfg(const IGemmParams& p, const PatchGeom& q, double flops, double bytes, int Mtot, hipStream_t s) {
     constexpr int BN = WAVES_N * WN * 32;
     int ppix = 0;
     for (int i = 0; i < q.ncls; ++i) ppix = q.c[i].PH * q.c[i].PW > ppix ? q.c[i].PH * q.c[i].PW : ppix;
-    const size_t lds = ((size_t)2 * BN + (size_t)ppix) * 36 * sizeof(float);
+    const size_t lds = ((size_t)2 * BN + (size_t)ppix) * (BF16 ? 40 * 2 : 36 * sizeof(float));
     static size_t attr_lds = 0;
-    auto kern = pgemm_kernel<TH_, TW_, WAVES_M, WAVES_N, WM, WN, MAXPL>;
+    auto kern = pgemm_kernel<TH_, TW_, WAVES_M, WAVES_N, WM, WN, MAXPL, BF16>;
     if (lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
@@ -691,7 +728,7 @@ static int launch_pgemm_cfg(const IGemmParams& p, const PatchGeom& q, double flo
     }
     dim3 grid(q.total_work, 1, p.splits);
     {
-        ProfScope ps(s, 0, flops, bytes, Mtot, p.N, p.Ktot, p.C, p.splits, 1000 + BN);
+        ProfScope ps(s, BF16 ? 3 : 0, flops, bytes, Mtot, p.N, p.Ktot, p.C, p.splits, (BF16 ? 3000 : 1000) + BN);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p, q);
     }
     TG_CHECK_LAUNCH("pgemm_kernel");
@@ -759,8 +796,13 @@ static bool try_pgemm(IGemmParams* ps, int ncls, size_t ws_floats_avail, hipStre
     }
     q.chunks_per_split = cdiv(p.nchunks, splits);
     p.splits = cdiv(p.nchunks, q.chunks_per_split);
-    if (n64) *rc = launch_pgemm_cfg<16, 16, 4, 1, 2, 2, 12>(p, q, flops, bytes, Mtot, s);
-    else *rc = launch_pgemm_cfg<8, 16, 2, 2, 2, 2, 7>(p, q, flops, bytes, Mtot, s);
+    if (p.bf16) {
+        if (n64) *rc = launch_pgemm_cfg<16, 16, 4, 1, 2, 2, 12, true>(p, q, flops, bytes, Mtot, s);
+        else *rc = launch_pgemm_cfg<8, 16, 2, 2, 2, 2, 7, true>(p, q, flops, bytes, Mtot, s);
+    } else {
+        if (n64) *rc = launch_pgemm_cfg<16, 16, 4, 1, 2, 2, 12, false>(p, q, flops, bytes, Mtot, s);
+        else *rc = launch_pgemm_cfg<8, 16, 2, 2, 2, 2, 7, false>(p, q, flops, bytes, Mtot, s);
+    }
     return true;
 }
 
@@ -849,6 +891,7 @@ extern "C" int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask
     p.KW = g->k; p.kstep = 1; p.ky0 = 0; p.kx0 = 0;
     p.Kfull = g->k * g->k * g->Cin;
     p.act = act; p.slope = slope; p.accumulate = 0;
+    p.bf16 = g->precision == TG_PREC_BF16;
     p.Ktot = p.TH * p.TW * p.C; p.nchunks = cdiv(p.C, 32);
     p.T = (p.C % 4) ? cdiv(p.Ktot, 32) : p.TH * p.TW * p.nchunks;
     plan_splits(p, ws ? ws_bytes / sizeof(float) : 0);
@@ -930,6 +973,7 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, con
             p.Kfull = taps * g->Cout;
             p.act = TG_ACT_NONE; p.slope = 0.f; p.accumulate = accumulate;
             p.gate = gate; p.gate_act = gate_act; p.gate_slope = gate_slope;
+            p.bf16 = g->precision == TG_PREC_BF16;
             p.Ktot = p.TH * p.TW * p.C; p.nchunks = cdiv(p.C, 32);
             p.T = (p.C % 4) ? cdiv(p.Ktot, 32) : p.TH * p.TW * p.nchunks;
             if (mergeable) {

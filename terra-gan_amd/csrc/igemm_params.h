@@ -21,6 +21,7 @@ struct IGemmParams {
     int act;
     float slope;
     int accumulate;
+    int bf16;               // operands rounded to bf16 at LDS staging, v_mfma_f32_32x32x16_bf16 (patch kernel only)
     const float* gate;      // optional [dst pixels][N]: result *= act'(gate) (fused activation backward)
     int gate_act;
     float gate_slope;

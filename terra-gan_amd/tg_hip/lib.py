@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libterragan_hip.so")
 
 
 class TgConv(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "k", "stride", "pad")]
+    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "k", "stride", "pad", "precision")]
 
 
 class TgError(RuntimeError):

@@ -8,6 +8,19 @@ import torch
 from . import lib as L
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+PREC_F32, PREC_BF16 = 0, 1
+_precision = PREC_F32
+
+
+def set_precision(name):
+    """'f32' (default) or 'bf16': arithmetic of the conv inner products (bf16 operands, fp32 accumulate; everything in
+    memory stays fp32).  Process-wide switch used by bench.py / train(config) for BASELINE config 3."""
+    global _precision
+    _precision = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16}[name]
+
+
+def get_precision():
+    return "bf16" if _precision == PREC_BF16 else "f32"
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
 
 _ws = {}
@@ -69,7 +82,7 @@ def weight_view(w):
 def conv_geom(x, cout, k, stride, pad):
     B, H, W, Cin = x.shape
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    return L.TgConv(B, H, W, Cin, Ho, Wo, cout, k, stride, pad)
+    return L.TgConv(B, H, W, Cin, Ho, Wo, cout, k, stride, pad, _precision)
 
 
 def conv_fwd(x, w, bias, k, stride, pad, in_mask=None, ratio=None, act=ACT_NONE, slope=0.0):
@@ -93,7 +106,7 @@ def conv_dgrad(dy, w, x_shape, k, stride, pad, in_mask=None, out=None, gate=None
     _chk(dy, "dy"); _chk(in_mask, "in_mask"); _chk(out, "out"); _chk(gate, "gate")
     wv = weight_view(w)
     B, H, W, Cin = x_shape
-    g = L.TgConv(B, H, W, Cin, dy.shape[1], dy.shape[2], dy.shape[3], k, stride, pad)
+    g = L.TgConv(B, H, W, Cin, dy.shape[1], dy.shape[2], dy.shape[3], k, stride, pad, _precision)
     acc = 1 if out is not None else 0
     dx = out if out is not None else empty(B, H, W, Cin, like=dy)
     lib = _lib()

@@ -44,8 +44,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
     args = ap.parse_args()
     lib = L.load()
+    O.set_precision(args.precision)
     dev = torch.device("cuda:0")
     only = set(filter(None, args.only.split(",")))
     print(f"{'layer':8s} {'op':6s} {'ms':>8s} {'TF':>7s} {'algGB/s':>8s}")
@@ -76,7 +78,8 @@ def main():
             ms0, n0, fl0, by0 = summary(lib, 0)
             ms1, n1, fl1, by1 = summary(lib, 1)
             ms2, n2, fl2, by2 = summary(lib, 2)
-            ms, fl, by = ms0 + ms1 + ms2, fl0 + fl1 + fl2, by0 + by1 + by2
+            ms3, n3, fl3, by3 = summary(lib, 3)
+            ms, fl, by = ms0 + ms1 + ms2 + ms3, fl0 + fl1 + fl2 + fl3, by0 + by1 + by2 + by3
             print(f"{name:8s} {op:6s} {ms / args.reps:8.3f} {fl / ms / 1e9 if ms else 0:7.1f} {by / ms / 1e6 if ms else 0:8.1f}", flush=True)
 
 

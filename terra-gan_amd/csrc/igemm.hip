@@ -144,7 +144,7 @@ __device__ __forceinline__ size_t dst_pixel(const IGemmParams& p, int m) {
     return ((size_t)b * p.DH + (oy * p.ds + p.dy0)) * p.DW + (ox * p.ds + p.dx0);
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR>
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, LDK = 36;
     constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
@@ -152,6 +152,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                 // [2][BM][LDK]
     float* Bs = smem + 2 * BM * LDK;  // [2][BN][LDK]
+    constexpr int LDH = 40;           // bf16 variant: [2][BM][LDH] + [2][BN][LDH] bf16 (see pgemm_kernel)
+    __bf16* Ah = reinterpret_cast<__bf16*>(smem);
+    __bf16* Bh = Ah + 2 * BM * LDH;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -277,6 +280,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
         }
     };
     auto sstore = [&](int buf) {
+        if constexpr (BF16) {
+            __bf16* Ab = Ah + buf * BM * LDH;
+            __bf16* Bb = Bh + buf * BN * LDH;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i)
+                *reinterpret_cast<bf16x4*>(Ab + (r0 + 32 * i) * LDH + 4 * kc) = __builtin_convertvector(ra[i], bf16x4);
+#pragma unroll
+            for (int j = 0; j < B_LOADS; ++j)
+                *reinterpret_cast<bf16x4*>(Bb + (r0 + 32 * j) * LDH + 4 * kc) = __builtin_convertvector(rw[j], bf16x4);
+            return;
+        }
         float* Ab = As + buf * BM * LDK;
         float* Bb = Bs + buf * BN * LDK;
 #pragma unroll
@@ -311,6 +325,30 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
             } else {
                 if (more) gbegin();
             }
+            if constexpr (BF16) {
+                if constexpr (!SCALAR) {
+                    if (more) {
+#pragma unroll
+                        for (int part = 0; part < 4; ++part) gpart(part);
+                    }
+                }
+                const __bf16* Ab = Ah + cur * BM * LDH;
+                const __bf16* Bb = Bh + cur * BN * LDH;
+                const int kh8 = 8 * (lane >> 5);
+#pragma unroll
+                for (int gk = 0; gk < 2; ++gk) {
+                    bf16x8 ah[WM], bh[WN];
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) ah[i] = *reinterpret_cast<const bf16x8*>(Ab + (arow + 32 * i) * LDH + 16 * gk + kh8);
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) bh[j] = *reinterpret_cast<const bf16x8*>(Bb + (brow + 32 * j) * LDH + 16 * gk + kh8);
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+            } else {
             const float* Ab = As + cur * BM * LDK;
             const float* Bb = Bs + cur * BN * LDK;
             // operand fragments are double-buffered in registers: the LDS reads of k-group g+1 are issued before the
@@ -343,6 +381,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
                         for (int j = 0; j < WN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg & 1][i][e], b[kg & 1][j][e], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
             if (more) sstore(cur ^ 1);
             __syncthreads();
@@ -402,12 +441,12 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IGemmParams p
     }
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR>
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR, bool BF16 = false>
 static int launch_igemm_cfg(const IGemmParams& p, hipStream_t s) {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
-    constexpr size_t lds = (size_t)2 * (BM + BN) * 36 * sizeof(float);
+    constexpr size_t lds = (size_t)2 * (BM + BN) * (BF16 ? 40 * 2 : 36 * sizeof(float));
     static bool attr_done = false;
-    auto kern = igemm_kernel<WAVES_M, WAVES_N, WM, WN, SCALAR>;
+    auto kern = igemm_kernel<WAVES_M, WAVES_N, WM, WN, SCALAR, BF16>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -422,7 +461,8 @@ static int launch_igemm_cfg(const IGemmParams& p, hipStream_t s) {
         // algorithmic bytes: source pixels touched once + row scale/mask + weights + output
         const double by = 4.0 * ((double)p.B * p.IH * p.IW * p.C + (double)p.M + (double)p.N * p.Ktot + (double)p.M * p.N +
                                  (p.amask ? (double)p.B * p.IH * p.IW : 0.0));
-        ProfScope ps(s, 0, 2.0 * p.M * (double)p.N * p.Ktot, by, p.M, p.N, p.Ktot, p.C, p.splits, BN + (SCALAR ? 1 : 0));
+        ProfScope ps(s, BF16 ? 3 : 0, 2.0 * p.M * (double)p.N * p.Ktot, by, p.M, p.N, p.Ktot, p.C, p.splits,
+                     (BF16 ? 3000 : 0) + BN + (SCALAR ? 1 : 0));
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     }
     TG_CHECK_LAUNCH("igemm_kernel");
@@ -845,6 +885,10 @@ static int launch_igemm(IGemmParams& p, hipStream_t s, size_t ws_floats_avail = 
         if (bn == 64) return launch_igemm_cfg<2, 2, 2, 1, true>(p, s);
         return launch_igemm_cfg<4, 1, 1, 1, true>(p, s);
     }
+    if (p.bf16) {
+        if (bn == 128) return launch_igemm_cfg<2, 2, 2, 2, false, true>(p, s);
+        if (bn == 64) return launch_igemm_cfg<2, 2, 2, 1, false, true>(p, s);
+    }
     if (bn == 128) return launch_igemm_cfg<2, 2, 2, 2, false>(p, s);
     if (bn == 64) return launch_igemm_cfg<2, 2, 2, 1, false>(p, s);
     return launch_igemm_cfg<4, 1, 1, 1, false>(p, s);
@@ -1231,6 +1275,182 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         }
 }
 
+// bf16-operand wgrad (BASELINE config 3).  Same GEMM view (M = Cout, N = (tap,c), K = pixels) but the MFMA wants 8
+// consecutive k (pixels) per lane for a fixed row, while memory is pixel-major.  The transpose happens at staging: a
+// thread takes TWO consecutive pixels x 4 channels (two 16-byte loads), rounds to bf16 and writes 4 dwords, each
+// holding {pixel k, pixel k+1} of one channel, into k-contiguous rows [row][32 pixels + 8 pad].  Requires Cout % 4 == 0,
+// C % 4 == 0 and row-segment addressing (Wo % 32 == 0).
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradParams p) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, BK = 32, LDH = 40;
+    constexpr int A_IT = 16 * (BM / 4) / 256;     // (pixel pair, channel quad) items per thread
+    constexpr int B_IT = 16 * (BN / 4) / 256;
+    static_assert(WAVES_M * WAVES_N == 4 && BN == 128, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* Ah = reinterpret_cast<__bf16*>(smem);     // [2][BM][LDH]
+    __bf16* Bh = Ah + 2 * BM * LDH;                   // [2][BN][LDH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int work = xcd_remap(blockIdx.x, p.nx * p.ny * p.splits);
+    const int bz = work / (p.nx * p.ny);
+    const int bxy = work - bz * (p.nx * p.ny);
+    const int n0 = (bxy % p.nx) * BN, c0m = (bxy / p.nx) * BM;
+    const int t_begin = bz * p.steps_per_split;
+    const int t_end = min(p.T, t_begin + p.steps_per_split);
+
+    // B' items: quad = idx % 32 (4 columns of the N tile), pair = idx / 32 (pixels 2*pair, 2*pair+1 of the step)
+    int bky[B_IT], bkx[B_IT], bc[B_IT], bpair[B_IT], bq[B_IT];
+    bool bv[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int idx = tid + 256 * i;
+        bq[i] = idx & 31;
+        bpair[i] = idx >> 5;
+        const int n = n0 + 4 * bq[i];
+        bv[i] = n < p.Ktot;
+        const int nn = bv[i] ? n : 0;
+        const int tap = nn / p.C;
+        bc[i] = nn - tap * p.C;
+        bky[i] = tap / p.k - p.pad;
+        bkx[i] = tap % p.k - p.pad;
+    }
+    int rs_ox0 = (t_begin * BK) % p.Wo, rs_oy = ((t_begin * BK) / p.Wo) % p.Ho, rs_b = (t_begin * BK) / p.Wo / p.Ho;
+
+    f32x4 ra[A_IT][2], rb[B_IT][2];
+    auto gload = [&](int t) {
+        const int mbase = t * BK;
+        constexpr int AQ = BM / 4;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int idx = tid + 256 * i;
+            const int quad = idx % AQ, pair = idx / AQ;
+            const int co = c0m + 4 * quad;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int m = mbase + 2 * pair + e;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m < p.Mpix && co < p.Cout) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + co);
+                ra[i][e] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int iy = rs_oy * p.stride + bky[i];
+            const bool vy = bv[i] && iy >= 0 && iy < p.H && mbase < p.Mpix;
+            const size_t rowoff = ((size_t)rs_b * p.H + (vy ? iy : 0)) * p.W;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int ix = (rs_ox0 + 2 * bpair[i] + e) * p.stride + bkx[i];
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (vy && ix >= 0 && ix < p.W) {
+                    const size_t pix = rowoff + ix;
+                    v = *reinterpret_cast<const f32x4*>(p.x + pix * p.C + bc[i]);
+                    if (p.amask) v *= p.amask[pix];
+                }
+                rb[i][e] = v;
+            }
+        }
+        rs_ox0 += BK;
+        if (rs_ox0 >= p.Wo) {
+            rs_ox0 = 0;
+            if (++rs_oy == p.Ho) { rs_oy = 0; ++rs_b; }
+        }
+    };
+    auto pack2 = [](float lo, float hi) -> uint32_t {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 v = {lo, hi};
+        bf16x2 h = __builtin_convertvector(v, bf16x2);
+        return *reinterpret_cast<uint32_t*>(&h);
+    };
+    auto sstore = [&](int buf) {
+        uint32_t* Ab = reinterpret_cast<uint32_t*>(Ah + buf * BM * LDH);
+        uint32_t* Bb = reinterpret_cast<uint32_t*>(Bh + buf * BN * LDH);
+        constexpr int AQ = BM / 4;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int idx = tid + 256 * i;
+            const int quad = idx % AQ, pair = idx / AQ;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Ab[(4 * quad + c) * (LDH / 2) + pair] = pack2(ra[i][0][c], ra[i][1][c]);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Bb[(4 * bq[i] + c) * (LDH / 2) + bpair[i]] = pack2(rb[i][0][c], rb[i][1][c]);
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int arow = wm * WM * 32 + (lane & 31), brow = wn * WN * 32 + (lane & 31);
+    const int kh8 = 8 * (lane >> 5);
+
+    if (t_begin < t_end) {
+        gload(t_begin);
+        sstore(0);
+        __syncthreads();
+        for (int t = t_begin; t < t_end; ++t) {
+            const int cur = (t - t_begin) & 1;
+            const bool more = (t + 1) < t_end;
+            if (more) gload(t + 1);
+            const __bf16* Ab = Ah + cur * BM * LDH;
+            const __bf16* Bb = Bh + cur * BN * LDH;
+#pragma unroll
+            for (int gk = 0; gk < 2; ++gk) {
+                bf16x8 ah[WM], bh[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) ah[i] = *reinterpret_cast<const bf16x8*>(Ab + (arow + 32 * i) * LDH + 16 * gk + kh8);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bh[j] = *reinterpret_cast<const bf16x8*>(Bb + (brow + 32 * j) * LDH + 16 * gk + kh8);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) sstore(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    float* out = p.out + (size_t)bz * p.Cout * p.Ktot;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int co = c0m + (wm * WM + i) * 32 + row;
+            if (co >= p.Cout) continue;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
+                if (n < p.Ktot) out[(size_t)co * p.Ktot + n] = acc[i][j][r];
+            }
+        }
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+static int launch_wgrad_bf16_cfg(const WgradParams& p, hipStream_t s) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * 40 * 2;
+    WgradParams pp = p;
+    pp.rowseg = 1;
+    pp.nx = cdiv(p.Ktot, BN);
+    pp.ny = cdiv(p.Cout, BM);
+    dim3 grid(pp.nx * pp.ny * p.splits);
+    {
+        const double by = 4.0 * ((double)p.B * p.H * p.W * p.C + (double)p.Mpix * p.Cout + (double)p.Cout * p.Ktot +
+                                 (double)p.Mpix + (p.amask ? (double)p.B * p.H * p.W : 0.0));
+        ProfScope ps(s, 3, 2.0 * p.Mpix * (double)p.Cout * p.Ktot, by, p.Cout, p.Ktot, p.Mpix, p.C, p.splits, 3500 + BM);
+        hipLaunchKernelGGL((wgrad_bf16_kernel<WAVES_M, WAVES_N, WM, WN>), grid, dim3(256), lds, s, pp);
+    }
+    TG_CHECK_LAUNCH("wgrad_bf16_kernel");
+    return TG_OK;
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                           size_t n, int splits) {
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
@@ -1336,7 +1556,10 @@ extern "C" int tg_conv_wgrad(const TgConv* g, const float* x, const float* in_ma
     p.out = p.splits > 1 ? ws : dw;
     const int bm = wgrad_bm(g);
     const bool sb = (g->Cin % 4) != 0;
-    if (bm == 128) rc = launch_wgrad_cfg<2, 2, 2, 2, false, false>(p, s);
+    const bool bf = g->precision == TG_PREC_BF16 && !sb && g->Cout % 4 == 0 && g->Wo % 32 == 0 && bm >= 64 && !getenv("TG_NO_BF16_WGRAD");
+    if (bf && bm == 128) rc = launch_wgrad_bf16_cfg<2, 2, 2, 2>(p, s);
+    else if (bf) rc = launch_wgrad_bf16_cfg<1, 4, 2, 1>(p, s);
+    else if (bm == 128) rc = launch_wgrad_cfg<2, 2, 2, 2, false, false>(p, s);
     else if (bm == 64) rc = sb ? launch_wgrad_cfg<1, 4, 2, 1, false, true>(p, s) : launch_wgrad_cfg<1, 4, 2, 1, false, false>(p, s);
     else rc = sb ? launch_wgrad_cfg<1, 4, 1, 1, true, true>(p, s) : launch_wgrad_cfg<1, 4, 1, 1, true, false>(p, s);
     if (rc) return rc;

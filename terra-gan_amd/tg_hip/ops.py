@@ -127,7 +127,7 @@ def conv_wgrad(x, dy, w, k, stride, pad, in_mask=None, want_bias=True, dw_out=No
     _chk(x, "x"); _chk(dy, "dy"); _chk(in_mask, "in_mask")
     wv = weight_view(w)
     B, H, W, Cin = x.shape
-    g = L.TgConv(B, H, W, Cin, dy.shape[1], dy.shape[2], dy.shape[3], k, stride, pad)
+    g = L.TgConv(B, H, W, Cin, dy.shape[1], dy.shape[2], dy.shape[3], k, stride, pad, _precision)
     if dw_out is not None:
         dwv = dw_out.permute(0, 2, 3, 1)
         assert dwv.is_contiguous() and dwv.shape == wv.shape

@@ -107,7 +107,7 @@ def main():
     from mvp_gan.src.models import Discriminator, PConvUNet
     from mvp_gan.src.train import train_step
     from mvp_gan.src.utils.losses import InpaintingLoss
-    from oracle.terragan_oracle import synth_batch       # input recipe only
+    from tg_hip.synth import synth_batch                   # seeded synthetic inputs (SURVEY §8d recipe)
     from tg_hip import lib as L
     from tg_hip.dist import GradSync
     lib = L.load()

@@ -100,3 +100,14 @@ def test_seeded_init_matches_reference():
     G2 = PConvUNet()
     G2.load_state_dict(sd)
     assert torch.equal(G2.enc2.input_conv.weight, w) and G2.enc2.input_conv.weight.permute(0, 2, 3, 1).is_contiguous()
+
+
+def test_bench_input_recipe_matches_oracle_copy():
+    """bench.py draws its synthetic tiles from tg_hip.synth (the product must not import oracle/); the oracle keeps its
+    own copy of the SURVEY §8d recipe for the fixtures.  They must agree bit for bit."""
+    from oracle import terragan_oracle as Orc
+    from tg_hip.synth import synth_batch
+    for b, size, seed in [(2, 64, 3), (1, 256, 1000)]:
+        a, m = synth_batch(b, size, seed)
+        a2, m2 = Orc.synth_batch(b, size, seed)
+        assert torch.equal(a, a2) and torch.equal(m, m2)

@@ -135,6 +135,36 @@ __device__ __forceinline__ int xcd_remap(int id, int total) {
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
 }
 
+// Epilogue helper.  The MFMA C layout gives a lane ONE column and 16 rows of a 32x32 tile, i.e. 16 single-dword
+// stores per tile and lane; such an epilogue is store-ISSUE bound (it cost the patch kernel ~6 K-steps per workgroup).
+// The wave bounces the tile through its own 32x36-float LDS scratch and comes back with 4 consecutive columns of one
+// row per lane: emit(row_in_tile, col_in_tile, f32x4) is called 4 times per lane -> 4 x 16-byte stores instead of
+// 16 x 4-byte ones.  A wave reads back only what it wrote itself (LDS ops of one wave complete in order): no barrier.
+template <class F>
+__device__ __forceinline__ void tile_rows4(float* scratch, const f32x16& acc, int lane, F&& emit) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[r];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int rr = (lane >> 3) + 8 * t;
+        emit(rr, 4 * (lane & 7), *reinterpret_cast<const f32x4*>(scratch + rr * 36 + 4 * (lane & 7)));
+    }
+}
+__device__ __forceinline__ f32x4 epilogue4(const IGemmParams& p, f32x4 o, size_t pix, int nb) {
+    const float rs = p.rowscale ? p.rowscale[pix] : 1.f;
+    if (p.bias) o += *reinterpret_cast<const f32x4*>(p.bias + nb);
+    o *= rs;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = apply_act(o[e], p.act, p.slope);
+    if (p.gate) {
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(p.gate + pix * p.N + nb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] *= gv[e] > 0.f ? 1.f : (p.gate_act == TG_ACT_LEAKY ? p.gate_slope : 0.f);
+    }
+    if (p.accumulate) o += *reinterpret_cast<const f32x4*>(p.dst + pix * p.N + nb);
+    return o;
+}
+
 __device__ __forceinline__ size_t dst_pixel(const IGemmParams& p, int m) {
     if (p.ds == 1 && p.OH == p.DH && p.OW == p.DW) return (size_t)m;
     int ox = m % p.OW;
@@ -388,6 +418,25 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
         }
     }
 
+    if ((p.N & 3) == 0) {     // wide stores (see tile_rows4); all waves are past the K loop's last barrier
+        float* scratch = smem + wave * (32 * 36);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                tile_rows4(scratch, acc[i][j], lane, [&](int rr, int cc, f32x4 v4) {
+                    const int m = m0 + (wm * WM + i) * 32 + rr;
+                    const int nb = n0 + (wn * WN + j) * 32 + cc;
+                    if (m >= p.M || nb >= p.N) return;
+                    if (p.splits > 1) {
+                        *reinterpret_cast<f32x4*>(p.ws + ((size_t)blockIdx.z * p.M + m) * p.N + nb) = v4;
+                    } else {
+                        const size_t pix = dst_pixel(p, m);
+                        *reinterpret_cast<f32x4*>(p.dst + pix * p.N + nb) = epilogue4(p, v4, pix, nb);
+                    }
+                });
+        return;
+    }
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
@@ -714,7 +763,28 @@ __global__ __launch_bounds__(256, 2) void pgemm_kernel(const IGemmParams p, cons
         }
     }
 
-    // epilogue: row r -> output pixel (oy0 + r / TW, ox0 + r % TW)
+    // epilogue: row r -> output pixel (oy0 + r / TW, ox0 + r % TW); wide stores via tile_rows4 when N % 4 == 0
+    if ((p.N & 3) == 0) {
+        float* scratch = smem + wave * (32 * 36);     // the K loop is over and every wave has passed its last barrier
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                tile_rows4(scratch, acc[i][j], lane, [&](int rr, int cc, f32x4 v4) {
+                    const int row = (wm * WM + i) * 32 + rr;
+                    const int nb = n0 + (wn * WN + j) * 32 + cc;
+                    const int oy = oy0 + row / TW_, ox = ox0 + row % TW_;
+                    if (oy >= g.OH || ox >= g.OW || nb >= p.N) return;
+                    if (p.splits > 1) {
+                        const size_t m = ((size_t)b * g.OH + oy) * g.OW + ox;
+                        *reinterpret_cast<f32x4*>(p.ws + ((size_t)blockIdx.z * p.M + m) * p.N + nb) = v4;
+                    } else {
+                        const size_t pix = ((size_t)b * p.DH + (oy * p.ds + g.dy0)) * p.DW + (ox * p.ds + g.dx0);
+                        *reinterpret_cast<f32x4*>(p.dst + pix * p.N + nb) = epilogue4(p, v4, pix, nb);
+                    }
+                });
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -1260,6 +1330,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
 
     float* out = p.out + (size_t)bz * p.Cout * p.Ktot;
+    if ((p.Ktot & 3) == 0) {      // wide stores (see tile_rows4)
+        float* scratch = smem + wave * (32 * 36);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                tile_rows4(scratch, acc[i][j], lane, [&](int rr, int cc, f32x4 v4) {
+                    const int co = c0m + (wm * WM + i) * 32 + rr;
+                    const int n = n0 + (wn * WN + j) * 32 + cc;
+                    if (co < p.Cout && n < p.Ktot) *reinterpret_cast<f32x4*>(out + (size_t)co * p.Ktot + n) = v4;
+                });
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1417,6 +1500,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradParams p)
         }
     }
     float* out = p.out + (size_t)bz * p.Cout * p.Ktot;
+    if ((p.Ktot & 3) == 0) {      // wide stores (see tile_rows4)
+        float* scratch = smem + wave * (32 * 36);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                tile_rows4(scratch, acc[i][j], lane, [&](int rr, int cc, f32x4 v4) {
+                    const int co = c0m + (wm * WM + i) * 32 + rr;
+                    const int n = n0 + (wn * WN + j) * 32 + cc;
+                    if (co < p.Cout && n < p.Ktot) *reinterpret_cast<f32x4*>(out + (size_t)co * p.Ktot + n) = v4;
+                });
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll

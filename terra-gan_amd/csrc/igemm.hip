@@ -475,6 +475,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
 // split-K second pass: fixed-order sum over the slabs + the same epilogue.
 __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IGemmParams p) {
     const size_t total = (size_t)p.M * p.N;
+    if ((p.N & 3) == 0) {
+        const size_t t4 = total >> 2;
+        for (size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x; i4 < t4; i4 += (size_t)gridDim.x * 256) {
+            const size_t idx = i4 * 4;
+            const int m = (int)(idx / p.N), n = (int)(idx - (size_t)m * p.N);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < p.splits; ++z) v += *reinterpret_cast<const f32x4*>(p.ws + (size_t)z * total + idx);
+            const size_t pix = dst_pixel(p, m);
+            *reinterpret_cast<f32x4*>(p.dst + pix * p.N + n) = epilogue4(p, v, pix, n);
+        }
+        return;
+    }
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int m = (int)(idx / p.N), n = (int)(idx - (size_t)m * p.N);
         float v = 0.f;
@@ -1549,6 +1561,15 @@ static int launch_wgrad_bf16_cfg(const WgradParams& p, hipStream_t s) {
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                           size_t n, int splits) {
+    if ((n & 3) == 0) {           // 16-byte accesses, fixed summation order over the slabs
+        const size_t n4 = n >> 2;
+        for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * 256) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < splits; ++z) v += reinterpret_cast<const f32x4*>(ws + (size_t)z * n)[idx];
+            reinterpret_cast<f32x4*>(out)[idx] = v;
+        }
+        return;
+    }
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
         float v = 0.f;
         for (int z = 0; z < splits; ++z) v += ws[(size_t)z * n + idx];
@@ -1661,7 +1682,7 @@ extern "C" int tg_conv_wgrad(const TgConv* g, const float* x, const float* in_ma
     if (rc) return rc;
     const size_t n = (size_t)g->Cout * p.Ktot;
     if (p.splits > 1) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid((int64_t)n, 256)), dim3(256), 0, s, ws, dw, n, p.splits);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(ew_grid((int64_t)((n & 3) ? n : n / 4), 256)), dim3(256), 0, s, ws, dw, n, p.splits);
         TG_CHECK_LAUNCH("slab_reduce_kernel");
     }
     if (db) {

@@ -621,8 +621,13 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict_
         const int b = (int)(t / H);
         float o[V];
         if (c >= Cu) {
+            if constexpr (V == 4) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(skip + pix * Cs + (c - Cu));
 #pragma unroll
-            for (int e = 0; e < V; ++e) o[e] = skip[pix * Cs + (c - Cu) + e];
+                for (int e = 0; e < 4; ++e) o[e] = t4[e];
+            } else {
+                o[0] = skip[pix * Cs + (c - Cu)];
+            }
         } else {
             const int yu = Y - offy, xu = X - offx;
             if (yu < 0 || yu >= 2 * h || xu < 0 || xu >= 2 * w) {
@@ -632,17 +637,28 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict_
                 const Lerp ly = lerp_src(yu, h), lx = lerp_src(xu, w);
                 const float* r0 = up + (((int64_t)b * h + ly.i0) * w) * Cu + c;
                 const float* r1 = up + (((int64_t)b * h + ly.i1) * w) * Cu + c;
+                float va[V], vb[V], vc[V], vd[V];
+                if constexpr (V == 4) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(r0 + (int64_t)lx.i0 * Cu), b4 = *reinterpret_cast<const f32x4*>(r0 + (int64_t)lx.i1 * Cu);
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(r1 + (int64_t)lx.i0 * Cu), d4 = *reinterpret_cast<const f32x4*>(r1 + (int64_t)lx.i1 * Cu);
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    float a = r0[(int64_t)lx.i0 * Cu + e], bb = r0[(int64_t)lx.i1 * Cu + e];
-                    float cc = r1[(int64_t)lx.i0 * Cu + e], d = r1[(int64_t)lx.i1 * Cu + e];
-                    o[e] = ly.l0 * (lx.l0 * a + lx.l1 * bb) + ly.l1 * (lx.l0 * cc + lx.l1 * d);
+                    for (int e = 0; e < 4; ++e) { va[e] = a4[e]; vb[e] = b4[e]; vc[e] = c4[e]; vd[e] = d4[e]; }
+                } else {
+                    va[0] = r0[(int64_t)lx.i0 * Cu]; vb[0] = r0[(int64_t)lx.i1 * Cu];
+                    vc[0] = r1[(int64_t)lx.i0 * Cu]; vd[0] = r1[(int64_t)lx.i1 * Cu];
                 }
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    o[e] = ly.l0 * (lx.l0 * va[e] + lx.l1 * vb[e]) + ly.l1 * (lx.l0 * vc[e] + lx.l1 * vd[e]);
             }
         }
         const float mk = omask ? omask[pix] : 1.f;
-#pragma unroll
-        for (int e = 0; e < V; ++e) out[pix * Ct + c + e] = o[e] * mk;
+        if constexpr (V == 4) {
+            const f32x4 o4 = {o[0] * mk, o[1] * mk, o[2] * mk, o[3] * mk};
+            *reinterpret_cast<f32x4*>(out + pix * Ct + c) = o4;
+        } else {
+            out[pix * Ct + c] = o[0] * mk;
+        }
     }
 }
 extern "C" int tg_upcat_fwd(const float* up, const float* skip, const float* out_mask, int B, int h, int w, int Cu, int H, int W,
@@ -690,12 +706,21 @@ __global__ __launch_bounds__(256) void upcat_bwd_up_kernel(const float* __restri
                 const float wx = (lx.i0 == x ? lx.l0 : 0.f) + (lx.i1 == x ? lx.l1 : 0.f);
                 if (wx == 0.f) continue;
                 const float* src = dout + (((int64_t)b * H + Y) * W + X) * Ct + c;
+                if constexpr (V == 4) {
+                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(src);
 #pragma unroll
-                for (int e = 0; e < V; ++e) acc[e] += wy * wx * src[e];
+                    for (int e = 0; e < 4; ++e) acc[e] += wy * wx * s4[e];
+                } else {
+                    acc[0] += wy * wx * src[0];
+                }
             }
         }
-#pragma unroll
-        for (int e = 0; e < V; ++e) dup[pix * Cu + c + e] = acc[e];
+        if constexpr (V == 4) {
+            const f32x4 a4 = {acc[0], acc[1], acc[2], acc[3]};
+            *reinterpret_cast<f32x4*>(dup + pix * Cu + c) = a4;
+        } else {
+            dup[pix * Cu + c] = acc[0];
+        }
     }
 }
 __global__ __launch_bounds__(256) void slice_channels_kernel(const float* __restrict__ src, int64_t rows, int Ct, int c0,

@@ -1565,6 +1565,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
         const size_t n4 = n >> 2;
         for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += (size_t)gridDim.x * 256) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
             for (int z = 0; z < splits; ++z) v += reinterpret_cast<const f32x4*>(ws + (size_t)z * n)[idx];
             reinterpret_cast<f32x4*>(out)[idx] = v;
         }

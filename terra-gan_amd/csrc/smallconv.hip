@@ -315,18 +315,23 @@ __global__ __launch_bounds__(256) void to1wgrad64_kernel(const WgradParams p, fl
     }
 }
 
+// second stage of the small wgrad kernels: 4 lanes share one output element and split the partial blocks (fixed order)
 __global__ __launch_bounds__(256) void smallconv_slab_reduce(const float* __restrict__ ws, float* __restrict__ out, size_t n,
                                                              int splits) {
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
-        double v = 0.0;
-        for (int z = 0; z < splits; ++z) v += (double)ws[(size_t)z * n + idx];
-        out[idx] = (float)v;
-    }
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t idx = gid >> 2;
+    const int part = (int)(gid & 3);
+    double v = 0.0;
+    if (idx < n)
+        for (int z = part; z < splits; z += 4) v += (double)ws[(size_t)z * n + idx];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    if (idx < n && part == 0) out[idx] = (float)v;
 }
 
 static int to1_wgrad_blocks(const WgradParams& p) {
     int blocks = cdiv(p.Mpix / 4, 64);
-    if (blocks > 256) blocks = 256;      // one resident workgroup per CU; keeps the second-stage sum short
+    if (blocks > 1024) blocks = 1024;    // 4 resident workgroups per CU: the loop is latency-bound with fewer
     if (blocks < 1) blocks = 1;
     return blocks;
 }
@@ -373,7 +378,7 @@ int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream
         TG_CHECK_LAUNCH("to1wgrad64_kernel");
     }
     const size_t n = (size_t)p.Cout * p.k * p.k * p.C;
-    hipLaunchKernelGGL(smallconv_slab_reduce, dim3(ew_grid((int64_t)n, 256)), dim3(256), 0, s, ws, dw, n, nb);
+    hipLaunchKernelGGL(smallconv_slab_reduce, dim3((unsigned)cdiv64((int64_t)n * 4, 256)), dim3(256), 0, s, ws, dw, n, nb);
     TG_CHECK_LAUNCH("smallconv_slab_reduce");
     return TG_OK;
 }

@@ -181,8 +181,9 @@ int tg_bce_logits(const float* z, int64_t n, float target, float coef, const flo
 
 /* torch.optim.Adam defaults (main_pipeline.py:214-221; train.py:139-147): in-place update of
  * p, m (exp_avg), v (exp_avg_sq) from g*grad_scale with bias correction for `step` (1-based). */
-int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-            float beta2, float eps, int step, float grad_scale, tg_stream_t stream);
+/* lr/betas/eps are doubles: they are rounded to fp32 exactly where torch.optim.Adam rounds its Python floats. */
+int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+            double beta2, double eps, int step, float grad_scale, tg_stream_t stream);
 
 /* Multi-tensor form: ONE launch over a device-resident table of segments (whole parameter tensors) and a
  * device-resident work list of int32 pairs (segment index, chunk index); chunk c of a segment covers elements
@@ -195,7 +196,7 @@ typedef struct TgAdamSeg {
     int64_t n;
 } TgAdamSeg;
 int tg_adam_multi(const TgAdamSeg* segs_dev, const int32_t* work_dev, int nwork, int chunk_elems,
-                  float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                  double lr, double beta1, double beta2, double eps, int step, float grad_scale,
                   tg_stream_t stream);
 
 /* y = a*x + b*y elementwise (gradient accumulation / scaling glue). */

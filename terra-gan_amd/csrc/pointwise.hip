@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256) void mask_update_kernel(const float* __restric
         }
         const float on = s > 0.f ? 1.f : 0.f;
         mask_out[idx] = on;
-        ratio[idx] = (float)(k * k) / (s + 1e-8f) * on;
+        // pconv.py:39 evaluates `slide_winsize / (mask_sum + 1e-8)` as reciprocal(mask_sum + 1e-8) * slide_winsize
+        // (Tensor.__rtruediv__): two roundings -- reproduced so that the ratio is bit-identical to the reference
+        ratio[idx] = (1.0f / (s + 1e-8f)) * (float)(k * k) * on;
     }
 }
 extern "C" int tg_mask_update(const float* mask, int B, int H, int W, int k, int stride, int pad, int Ho, int Wo,
@@ -1127,24 +1129,26 @@ extern "C" int tg_bce_logits(const float* z, int64_t n, float target, float coef
 // =================================================================================================
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float one_minus_b1, float b2,
-                                                   float one_minus_b2, float step_size, float inv_bc2_sqrt, float eps,
+                                                   float one_minus_b2, float step_size, float bc2_sqrt, float eps,
                                                    float grad_scale) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float gr = g[i] * grad_scale;
         const float mi = m[i] + one_minus_b1 * (gr - m[i]);       // exp_avg.lerp_(grad, 1 - beta1)
         const float vi = v[i] * b2 + one_minus_b2 * gr * gr;      // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;           // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
         m[i] = mi;
         v[i] = vi;
         p[i] = p[i] - step_size * (mi / denom);
     }
 }
-extern "C" int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+// Scalars are taken as doubles and rounded to fp32 exactly where torch.optim.Adam rounds its Python floats
+// (lerp weight 1-beta1, mul_ by beta2, addcmul_ value 1-beta2, addcdiv_ value -lr/bc1, division by sqrt(bc2)).
+extern "C" int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                        int step, float grad_scale, tg_stream_t stream) {
     TG_REQUIRE(p && g && m && v && n > 0 && step >= 1, "tg_adam: bad arguments");
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), p, g, m, v, n, 1.f - beta1, beta2,
-                       1.f - beta2, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps, grad_scale);
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps, grad_scale);
     TG_CHECK_LAUNCH("adam_kernel");
     return TG_OK;
 }
@@ -1153,7 +1157,7 @@ extern "C" int tg_adam(float* p, const float* g, float* m, float* v, int64_t n, 
 // elements [chunk*chunk_elems, ...) of segment seg (both packed in `work`)
 __global__ __launch_bounds__(256) void adam_multi_kernel(const TgAdamSeg* __restrict__ segs, const int32_t* __restrict__ work,
                                                          int chunk_elems, float one_minus_b1, float b2, float one_minus_b2,
-                                                         float step_size, float inv_bc2_sqrt, float eps, float grad_scale) {
+                                                         float step_size, float bc2_sqrt, float eps, float grad_scale) {
     const int seg = work[2 * blockIdx.x], chunk = work[2 * blockIdx.x + 1];
     const TgAdamSeg sg = segs[seg];
     const int64_t begin = (int64_t)chunk * chunk_elems;
@@ -1171,7 +1175,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const TgAdamSeg* __rest
                 const float gr = g4[e] * grad_scale;
                 m4[e] = m4[e] + one_minus_b1 * (gr - m4[e]);
                 v4[e] = v4[e] * b2 + one_minus_b2 * gr * gr;
-                p4[e] = p4[e] - step_size * (m4[e] / (sqrtf(v4[e]) * inv_bc2_sqrt + eps));
+                p4[e] = p4[e] - step_size * (m4[e] / (sqrtf(v4[e]) / bc2_sqrt + eps));
             }
             *reinterpret_cast<f32x4*>(sg.m + i) = m4;
             *reinterpret_cast<f32x4*>(sg.v + i) = v4;
@@ -1183,18 +1187,18 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const TgAdamSeg* __rest
         const float gr = sg.g[i] * grad_scale;
         const float mi = sg.m[i] + one_minus_b1 * (gr - sg.m[i]);
         const float vi = sg.v[i] * b2 + one_minus_b2 * gr * gr;
-        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
         sg.m[i] = mi;
         sg.v[i] = vi;
         sg.p[i] = sg.p[i] - step_size * (mi / denom);
     }
 }
-extern "C" int tg_adam_multi(const TgAdamSeg* segs_dev, const int32_t* work_dev, int nwork, int chunk_elems, float lr, float beta1,
-                             float beta2, float eps, int step, float grad_scale, tg_stream_t stream) {
+extern "C" int tg_adam_multi(const TgAdamSeg* segs_dev, const int32_t* work_dev, int nwork, int chunk_elems, double lr, double beta1,
+                             double beta2, double eps, int step, float grad_scale, tg_stream_t stream) {
     TG_REQUIRE(segs_dev && work_dev && nwork > 0 && chunk_elems > 0 && step >= 1, "tg_adam_multi: bad arguments");
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    hipLaunchKernelGGL(adam_multi_kernel, dim3(nwork), dim3(256), 0, S(stream), segs_dev, work_dev, chunk_elems, 1.f - beta1, beta2,
-                       1.f - beta2, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps, grad_scale);
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(nwork), dim3(256), 0, S(stream), segs_dev, work_dev, chunk_elems, (float)(1.0 - beta1),
+                       (float)beta2, (float)(1.0 - beta2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps, grad_scale);
     TG_CHECK_LAUNCH("adam_multi_kernel");
     return TG_OK;
 }

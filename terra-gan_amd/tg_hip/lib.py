@@ -19,7 +19,7 @@ class TgError(RuntimeError):
     pass
 
 
-P, I, I64, F, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+P, I, I64, F, SZ, D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_double
 CP = C.POINTER(TgConv)
 
 # name -> (restype, argtypes); mirrors include/terragan_hip.h line by line
@@ -53,8 +53,8 @@ SIGNATURES = {
     "tg_reduce_ws_bytes": (SZ, [I64]),
     "tg_l1_mean": (I, [P, P, I64, F, P, P, P, P, SZ, P]),
     "tg_bce_logits": (I, [P, I64, F, F, P, P, P, P, SZ, P]),
-    "tg_adam": (I, [P, P, P, P, I64, F, F, F, F, I, F, P]),
-    "tg_adam_multi": (I, [P, P, I, I, F, F, F, F, I, F, P]),
+    "tg_adam": (I, [P, P, P, P, I64, D, D, D, D, I, F, P]),
+    "tg_adam_multi": (I, [P, P, I, I, D, D, D, D, I, F, P]),
     "tg_axpby": (I, [P, F, F, P, I64, P]),
     "tg_lincomb": (I, [P, F, P, F, P, I64, P]),
     "tg_mul": (I, [P, P, P, I64, P]),

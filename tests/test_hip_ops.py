@@ -1,0 +1,217 @@
+"""Op-level parity of the C ABI against plain PyTorch-CPU fp32 references at awkward shapes: channel counts that are not
+multiples of 4 (scalar fallbacks), odd spatial sizes, strides/kernels outside the network's own set, tiny and empty-ish
+masks.  These paths are not exercised by the train step itself."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from tg_hip import lib
+    lib.load()
+    return torch.device("cuda:0")
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    assert err <= atol + rtol * b.abs().max().item(), f"max err {err:.3e} (ref max {b.abs().max().item():.3e})"
+
+
+CONVS = [  # B, H, W, Cin, Cout, k, s, p
+    (2, 13, 17, 3, 5, 3, 1, 1),       # odd everything, scalar K path, N < 32
+    (2, 16, 16, 6, 34, 3, 2, 1),      # C % 4 != 0, N not a tile multiple
+    (1, 9, 31, 8, 96, 5, 2, 2),       # N = 96 (64-tile + guard)
+    (3, 20, 12, 32, 64, 1, 1, 0),     # 1x1 conv
+    (2, 24, 40, 64, 64, 3, 1, 1),     # patch kernel, OW not a multiple of 16
+    (2, 17, 33, 128, 128, 3, 1, 1),   # patch kernel 128-config with overhanging tiles
+    (2, 32, 32, 64, 192, 4, 2, 1),    # stride-2 k4 (merged parity classes in dgrad)
+    (1, 8, 8, 512, 512, 3, 1, 1),     # small spatial, split-K
+    (2, 10, 10, 16, 16, 3, 3, 0),     # stride 3 (9 dgrad classes, not merged)
+    (2, 16, 32, 1, 64, 3, 1, 1),      # 1 -> 64 (c1conv)
+    (2, 16, 32, 64, 1, 3, 1, 1),      # 64 -> 1 (to1conv64)
+    (2, 12, 20, 1, 128, 4, 2, 1),     # 1 -> 128, two channel groups
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS, ids=[f"{c[3]}to{c[4]}_k{c[5]}s{c[6]}_{c[1]}x{c[2]}" for c in CONVS])
+def test_conv_fwd_dgrad_wgrad(dev, cfg):
+    from tg_hip import ops as O
+    B, H, W, Cin, Cout, k, s, p = cfg
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    m = (torch.rand(B, 1, H, W, generator=g) > 0.3).float()
+    ones = torch.ones(1, 1, k, k)
+    ssum = F.conv2d(m, ones, None, s, p)
+    ratio = (k * k) / (ssum + 1e-8) * (ssum > 0).float()
+    y_ref = F.leaky_relu((F.conv2d(x * m, w, b, s, p)) * ratio, 0.2)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+
+    xd, md = nhwc(x.detach()).to(dev), m[:, 0].contiguous().to(dev)
+    wd = w.detach().contiguous(memory_format=torch.channels_last).to(dev)
+    mo, rd = O.mask_update(md, k, s, p)
+    assert torch.equal(mo.cpu(), (ssum[:, 0] > 0).float()) and torch.equal(rd.cpu(), ratio[:, 0])       # integer mask path: exact
+    y = O.conv_fwd(xd, wd, b.detach().to(dev), k, s, p, in_mask=md, ratio=rd, act=O.ACT_LEAKY, slope=0.2)
+    close(nchw(y), y_ref)
+    # backward: dy_conv = gy * leaky'(y) * ratio
+    dyr = O.act_bwd(nhwc(gy).to(dev), y, O.ACT_LEAKY, 0.2, ratio=rd, inplace=False)
+    dx = O.conv_dgrad(dyr, wd, tuple(xd.shape), k, s, p, in_mask=md)
+    close(nchw(dx), x.grad, rtol=2e-4)
+    dw, db = O.conv_wgrad(xd, dyr, wd, k, s, p, in_mask=md)
+    close(dw, w.grad, rtol=2e-4, atol=1e-4)
+    close(db, b.grad, rtol=2e-4, atol=1e-4)
+    # accumulate + gated variants
+    base = torch.randn(xd.shape, generator=g).to(dev)
+    acc = O.conv_dgrad(dyr, wd, tuple(xd.shape), k, s, p, in_mask=md, out=base.clone())
+    close(acc, base + dx, rtol=2e-4)
+    gate = torch.randn(xd.shape, generator=g).to(dev)
+    gated = O.conv_dgrad(dyr, wd, tuple(xd.shape), k, s, p, in_mask=md, gate=gate, gate_act=O.ACT_RELU)
+    close(gated, dx * (gate > 0).float(), rtol=2e-4)
+
+
+@pytest.mark.parametrize("C,rows", [(1, 50), (3, 1000), (6, 77), (64, 4096), (192, 333), (512, 64), (1024, 7)])
+def test_batchnorm_fwd_bwd(dev, C, rows):
+    from tg_hip import ops as O
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(rows, C, generator=g) * 2 + 5).requires_grad_(True)     # mean >> 0: exercises the shifted sums
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, generator=g, requires_grad=True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    ratio = torch.rand(rows, generator=g) + 0.5
+    y = F.relu(F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5))
+    gy = torch.randn(rows, C, generator=g)
+    xin = x                                                   # y = BN(x); conv bias gradient = sum_rows ratio * dx_bn
+    y.backward(gy)
+    xd = x.detach().reshape(1, 1, rows, C).contiguous().to(dev)
+    rmd, rvd, nbt = torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros((), dtype=torch.long, device=dev)
+    mean, rstd = O.bn_stats(xd, rmd, rvd, nbt)
+    close(rmd, rm, rtol=1e-5, atol=1e-6)
+    close(rvd, rv, rtol=1e-5, atol=1e-6)
+    assert int(nbt) == 1
+    a = O.bn_act_fwd(xd, mean, rstd, gamma.detach().to(dev), beta.detach().to(dev), O.ACT_RELU)
+    close(a.reshape(rows, C), y)
+    dy, dgamma, dbeta, dbias = O.bn_act_bwd(gy.reshape(1, 1, rows, C).contiguous().to(dev), xd, mean, rstd, gamma.detach().to(dev),
+                                            beta.detach().to(dev), O.ACT_RELU, ratio=ratio.to(dev), inplace=False)
+    close(dy.reshape(rows, C), x.grad * ratio[:, None], rtol=2e-4, atol=1e-5)
+    close(dgamma, gamma.grad, rtol=2e-4, atol=1e-4)
+    close(dbeta, beta.grad, rtol=2e-4, atol=1e-4)
+    close(dbias, (x.grad * ratio[:, None]).sum(0), rtol=1e-3, atol=2e-3 * math.sqrt(rows))
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 8, 4), (1, 4, 4, 6, 3), (2, 9, 6, 64, 64), (2, 3, 5, 4, 0), (1, 1, 1, 5, 2)])
+@pytest.mark.parametrize("delta", [(0, 0), (1, 0), (-1, 1), (3, 2)])
+def test_upcat_fwd_bwd(dev, shape, delta):
+    """bilinear x2 + _pad_to_match (incl. negative = crop, generator.py:78-84) + concat + merged-mask multiply."""
+    from tg_hip import ops as O
+    B, h, w, Cu, Cs = shape
+    H, W = 2 * h + delta[0], 2 * w + delta[1]
+    if H < 1 or W < 1:
+        pytest.skip("empty")
+    g = torch.Generator().manual_seed(1)
+    up = torch.randn(B, Cu, h, w, generator=g, requires_grad=True)
+    skip = torch.randn(B, Cs, H, W, generator=g, requires_grad=True) if Cs else None
+    om = (torch.rand(B, 1, H, W, generator=g) > 0.3).float()
+    u = F.interpolate(up, scale_factor=2, mode="bilinear", align_corners=False)
+    dY, dX = H - u.shape[2], W - u.shape[3]
+    u = F.pad(u, [dX // 2, dX - dX // 2, dY // 2, dY - dY // 2])
+    ref = (torch.cat([u, skip], 1) if Cs else u) * om
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    out = O.upcat_fwd(nhwc(up.detach()).to(dev), nhwc(skip.detach()).to(dev) if Cs else None, H, W, out_mask=om[:, 0].contiguous().to(dev))
+    close(nchw(out), ref)
+    dup, dskip = O.upcat_bwd(nhwc(gy * om).to(dev), h, w, Cu)
+    close(nchw(dup), up.grad, rtol=2e-4)
+    if Cs:
+        close(nchw(dskip), skip.grad)
+    # nearest-up mask merge uses the same padding rule
+    um = (torch.rand(B, 1, h, w, generator=g) > 0.5).float()
+    sm = (torch.rand(B, 1, H, W, generator=g) > 0.5).float()
+    un = F.interpolate(um, scale_factor=2, mode="nearest")
+    un = F.pad(un, [dX // 2, dX - dX // 2, dY // 2, dY - dY // 2])
+    mm = O.mask_up_merge(um[:, 0].contiguous().to(dev), sm[:, 0].contiguous().to(dev))
+    assert torch.equal(mm.cpu(), torch.maximum(un, sm)[:, 0])
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 4), (1, 7, 9, 3), (2, 5, 6, 64), (1, 2, 2, 1)])
+def test_maxpool(dev, shape):
+    from tg_hip import ops as O
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(3)
+    x = F.relu(torch.randn(B, C, H, W, generator=g)).requires_grad_(True)       # post-ReLU input, ties at 0
+    y = F.max_pool2d(x, 2, 2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = nhwc(x.detach()).to(dev)
+    close(nchw(O.maxpool2_fwd(xd)), y, rtol=0, atol=0)
+    dx = O.maxpool2_bwd(nhwc(gy).to(dev), xd)
+    # ties among zeros may pick another zero than ATen; ReLU's backward kills those anyway
+    close(nchw(dx) * (x.detach() > 0).float().to(dev), x.grad * (x.detach() > 0).float(), rtol=0, atol=0)
+    dxg = O.maxpool2_bwd(nhwc(gy).to(dev), xd, relu_gate=True)
+    close(nchw(dxg), x.grad * (x.detach() > 0).float(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 2), (2, 33, 17), (3, 64, 64)])
+def test_pixel_losses_and_bce_shapes(dev, shape):
+    from oracle import terragan_oracle as Orc
+    from tg_hip import ops as O
+    B, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    pred = torch.rand(B, 1, H, W, generator=g, requires_grad=True)
+    tgt = torch.rand(B, 1, H, W, generator=g)
+    for kind in ("rand", "ones", "zeros"):
+        m = {"rand": (torch.rand(B, 1, H, W, generator=g) > 0.4).float(), "ones": torch.ones(B, 1, H, W), "zeros": torch.zeros(B, 1, H, W)}[kind]
+        pred.grad = None
+        tot = (pred - tgt).abs().mean() + 0.1 * Orc.tv_loss(pred * (1 - m)) + 0.5 * Orc.boundary_loss(pred, tgt, m)
+        tot.backward()
+        out5, dp = O.pixel_losses(pred.detach()[:, 0].contiguous().to(dev), tgt[:, 0].contiguous().to(dev), m[:, 0].contiguous().to(dev),
+                                  1.0, 0.1, 0.5)
+        close(out5[4], tot.detach(), rtol=1e-5, atol=1e-7)
+        close(dp, pred.grad[:, 0], rtol=1e-4, atol=1e-9)
+    z = torch.randn(B, H, W, generator=g) * 4
+    for t in (0.0, 1.0):
+        zz = z.clone().requires_grad_(True)
+        l = F.binary_cross_entropy_with_logits(zz, torch.full_like(zz, t))
+        l.backward()
+        lo, dz = O.bce_logits(z.to(dev), t)
+        close(lo[0], l.detach(), rtol=1e-5, atol=1e-7)
+        close(dz, zz.grad, rtol=1e-4, atol=1e-9)
+
+
+def test_adam_matches_torch(dev):
+    from mvp_gan.src.train import hip_adam_step
+    g = torch.Generator().manual_seed(9)
+    shapes = [(7,), (3, 5), (64, 3, 3, 3), (130, 1, 1, 1), (1,)]
+    p_ref = [torch.randn(s_, generator=g).requires_grad_(True) for s_ in shapes]
+    p_hip = [p.detach().clone().to(dev).requires_grad_(True) for p in p_ref]
+    o_ref, o_hip = torch.optim.Adam(p_ref, lr=3e-3), torch.optim.Adam(p_hip, lr=3e-3)
+    for step in range(4):
+        for pr, ph in zip(p_ref, p_hip):
+            gr = torch.randn(pr.shape, generator=g)
+            pr.grad, ph.grad = gr.clone(), gr.clone().to(dev)
+        o_ref.step()
+        hip_adam_step(o_hip)
+    for pr, ph in zip(p_ref, p_hip):
+        close(ph, pr, rtol=1e-6, atol=1e-7)
+        close(o_hip.state[ph]["exp_avg_sq"], o_ref.state[pr]["exp_avg_sq"], rtol=1e-6, atol=1e-12)
+    sd = o_hip.state_dict()                               # still a torch.optim.Adam state dict
+    torch.optim.Adam([torch.zeros(s_) for s_ in shapes], lr=3e-3).load_state_dict(
+        {"state": {k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in sd["state"].items()},
+         "param_groups": sd["param_groups"]})

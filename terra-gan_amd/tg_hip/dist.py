@@ -42,6 +42,11 @@ class GradSync:
     def grad_scale(self):
         return 1.0 / self.world_size
 
+    def _all_reduce(self, flat):
+        """SUM `flat` over the ranks in place, asynchronously; returns a handle with .wait().  The one place that
+        touches the transport (RCCL / gloo) -- tests substitute an in-process exchange here."""
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def _plan(self, module, tag):
         gb = grad_buffers(module)                 # shared with the backward kernels: gradients are born in `flat`
         plan = self._plans.get(tag)
@@ -76,7 +81,7 @@ class GradSync:
                     p.grad = view
             b = Bucket([p for p, _ in plist], flat[start:end])
             if self.world_size > 1:
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b.work = self._all_reduce(b.flat)
             out.append(b)
         return out
 

@@ -317,9 +317,16 @@ def gen_steps(ref_gen, ref_disc, ref_losses):
                 for n, buf in list(G.named_buffers()) + list(D.named_buffers()):
                     if "running" in n and n.split(".")[0] in ("enc1", "enc7", "dec1", "model"):
                         put(out, f"{tag}/s{s}/buf/{n}", buf, full_limit=1024)
-    # data-parallel emulation: N micro-batches, identical weights, mean grads, one Adam
+    out.update(gen_dp(ref_gen, ref_disc, ref_losses, [("dp2_128", 2, 4, 128)]))
+    return out
+
+
+def gen_dp(ref_gen, ref_disc, ref_losses, cases):
+    """Data-parallel emulation: N micro-batches, identical weights, mean grads, one Adam."""
     import copy
-    for tag, n, b, size in [("dp2_128", 2, 4, 128)]:
+    out = {}
+    bce = nn.BCEWithLogitsLoss()
+    for tag, n, b, size in cases:
         G, D, crit, oG, oD = _build(ref_gen, ref_disc, ref_losses)
         out[f"{tag}/cfg"] = np.array([n, b, size], dtype=np.int64)
         gens, gsum = [], {}
@@ -389,6 +396,7 @@ def main():
         "losses": lambda: gen_losses(ref_losses),
         "init": lambda: gen_init(ref_gen, ref_disc, ref_losses),
         "steps": lambda: gen_steps(ref_gen, ref_disc, ref_losses),
+        "steps_dp8": lambda: gen_dp(ref_gen, ref_disc, ref_losses, [("dp8_128", 8, 4, 128)]),
     }
     only = sys.argv[1:]
     for name, fn in jobs.items():

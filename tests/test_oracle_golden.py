@@ -174,14 +174,15 @@ def test_train_steps(tag):
             _check_weights(gold, f"{tag}/s{s}", st, 2e-4 * (s + 1))
 
 
-def test_dp_emulation():
-    gold = GU.load("steps")
-    n, b, size = [int(v) for v in gold["dp2_128/cfg"]]
+@pytest.mark.parametrize("fixture,tag", [("steps", "dp2_128"), ("steps_dp8", "dp8_128")])
+def test_dp_emulation(fixture, tag):
+    gold = GU.load(fixture)
+    n, b, size = [int(v) for v in gold[f"{tag}/cfg"]]
     st = O.TrainState(0)
     batches = [O.synth_batch(b, size, 1000 + r) for r in range(n)]
     gens, scal = O.dp_train_step(st, [x for x, _ in batches], [m for _, m in batches])
     for r in range(n):
         for k in ["g_total", "d_loss"]:
-            ref = float(gold[f"dp2_128/r{r}/{k}"])
+            ref = float(gold[f"{tag}/r{r}/{k}"])
             assert abs(float(scal[r][k]) - ref) <= 2e-6 * abs(ref) + 1e-7, (r, k)
-    _check_weights(gold, "dp2_128", st, 2e-4)
+    _check_weights(gold, tag, st, 2e-4)

@@ -928,6 +928,8 @@ static bool try_pgemm(IGemmParams* ps, int ncls, size_t ws_floats_avail, hipStre
     return true;
 }
 
+#include "wino.inc"
+
 static int pick_bn(int N) { return N >= 128 && N % 128 == 0 ? 128 : (N > 32 ? 64 : 32); }
 
 // K-split so that small-M layers (enc5-7, dec7, dec6) still fill 256 CUs.
@@ -953,6 +955,7 @@ static int launch_igemm(IGemmParams& p, hipStream_t s, size_t ws_floats_avail = 
         ProfScope ps(s, 2, 2.0 * p.M * (double)p.N * p.Ktot, by, p.M, p.N, p.Ktot, p.C, 1, 2000);
         return smallconv_fwd_launch(p, s);
     }
+    if (wino_ok(p)) return launch_wino(p, ws_floats_avail, s);
     {
         int rc = TG_OK;
         if (try_pgemm(&p, 1, ws_floats_avail, s, &rc)) return rc;
@@ -991,6 +994,13 @@ static int check_conv(const TgConv* g, const char* who) {
 }
 static bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
 
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// room for the Winograd-transformed weights of a stride-1 3x3 layer (0 when the layer can never take that path)
+static size_t conv_wino_floats(const TgConv* g) {
+    if (g->k != 3 || g->stride != 1 || (g->Cin % 8) != 0 || (g->Cout % 8) != 0) return 0;
+    return align_up(wino_u_floats(g->Cout, g->Cin), 64);
+}
+
 // ---- forward ----------------------------------------------------------------------------------
 extern "C" size_t tg_conv_fwd_ws_bytes(const TgConv* g) {
     if (!g) return 0;
@@ -998,7 +1008,7 @@ extern "C" size_t tg_conv_fwd_ws_bytes(const TgConv* g) {
     size_t out = (size_t)g->B * g->Ho * g->Wo * g->Cout;
     size_t cap = (size_t)64 << 20;  // floats
     size_t want = out * 16;
-    return (want < cap ? want : cap) * sizeof(float);
+    return ((want < cap ? want : cap) + conv_wino_floats(g)) * sizeof(float);
 }
 
 extern "C" int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* bias,
@@ -1020,8 +1030,20 @@ extern "C" int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask
     p.bf16 = g->precision == TG_PREC_BF16;
     p.Ktot = p.TH * p.TW * p.C; p.nchunks = cdiv(p.C, 32);
     p.T = (p.C % 4) ? cdiv(p.Ktot, 32) : p.TH * p.TW * p.nchunks;
-    plan_splits(p, ws ? ws_bytes / sizeof(float) : 0);
-    return launch_igemm(p, (hipStream_t)stream, ws ? ws_bytes / sizeof(float) : 0);
+    size_t ws_floats = ws ? ws_bytes / sizeof(float) : 0;
+    const size_t uf = conv_wino_floats(g);
+    if (uf && ws_floats >= uf && aligned16(ws)) {         // transformed weights live at the head of the workspace
+        p.w_raw = w; p.w_sn = (long)p.Kfull; p.w_sk = 1; p.w_stap = g->Cin;
+        p.wino_u = ws;
+        if (wino_ok(p)) {
+            p.ws = ws + uf;
+            ws_floats -= uf;
+        } else {
+            p.wino_u = nullptr;
+        }
+    }
+    plan_splits(p, ws_floats);
+    return launch_igemm(p, (hipStream_t)stream, ws_floats);
 }
 
 // ---- dgrad ---------------------------------------------------------------------------------------
@@ -1038,11 +1060,15 @@ __global__ __launch_bounds__(256) void transpose_w_kernel(const float* __restric
     }
 }
 
-static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
+// head of the dgrad workspace: the transposed weights, or (stride-1 3x3) the Winograd-transformed ones
+static size_t dgrad_wt_floats(const TgConv* g) {
+    size_t wt = align_up((size_t)g->Cout * g->k * g->k * g->Cin, 64);
+    size_t uf = conv_wino_floats(g);
+    return wt > uf ? wt : uf;
+}
 extern "C" size_t tg_conv_dgrad_ws_bytes(const TgConv* g) {
     if (!g) return 0;
-    size_t wt = align_up((size_t)g->Cout * g->k * g->k * g->Cin, 64);
+    size_t wt = dgrad_wt_floats(g);
     size_t out = (size_t)g->B * g->H * g->W * g->Cin;
     size_t cap = (size_t)64 << 20;
     size_t want = out * 16;
@@ -1067,15 +1093,31 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, con
     TG_REQUIRE(dy && w && dx && ws, "tg_conv_dgrad: null pointer");
     TG_REQUIRE(aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(ws), "tg_conv_dgrad: pointers must be 16-byte aligned");
     const int taps = g->k * g->k;
-    const size_t wt_floats = align_up((size_t)g->Cout * taps * g->Cin, 64);
+    const size_t wt_floats = dgrad_wt_floats(g);
     TG_REQUIRE(ws_bytes >= wt_floats * sizeof(float), "tg_conv_dgrad: workspace too small (%zu < %zu)", ws_bytes,
                wt_floats * sizeof(float));
     hipStream_t s = (hipStream_t)stream;
+    float* ws2 = ws + wt_floats;
+    const size_t ws2_floats = ws_bytes / sizeof(float) - wt_floats;
+    if (conv_wino_floats(g)) {
+        // stride-1 3x3: the Winograd kernel reads W[co][tap][ci] through strides (n = ci, k = co); no transposed copy
+        IGemmParams p = {};
+        p.src = dy; p.rowscale = in_mask; p.dst = dx; p.ws = ws2;
+        p.B = g->B; p.IH = g->Ho; p.IW = g->Wo; p.C = g->Cout;
+        p.OH = g->H; p.OW = g->W; p.N = g->Cin; p.M = g->B * g->H * g->W;
+        p.DH = g->H; p.DW = g->W; p.ds = 1;
+        p.ky0 = 0; p.kx0 = 0; p.TH = 3; p.TW = 3; p.ss = 1; p.tstep = -1; p.sy0 = g->pad; p.sx0 = g->pad;
+        p.KW = 3; p.kstep = 1; p.Kfull = taps * g->Cout;
+        p.act = TG_ACT_NONE; p.accumulate = accumulate;
+        p.gate = gate; p.gate_act = gate_act; p.gate_slope = gate_slope;
+        p.bf16 = g->precision == TG_PREC_BF16;
+        p.w_raw = w; p.w_sn = 1; p.w_sk = (long)taps * g->Cin; p.w_stap = g->Cin;
+        p.wino_u = ws;
+        if (wino_ok(p)) return launch_wino(p, ws2_floats, s);
+    }
     hipLaunchKernelGGL(transpose_w_kernel, dim3(ew_grid((int64_t)g->Cout * taps * g->Cin, 256)), dim3(256), 0, s, w, ws,
                        g->Cout, taps, g->Cin);
     TG_CHECK_LAUNCH("transpose_w_kernel");
-    float* ws2 = ws + wt_floats;
-    const size_t ws2_floats = ws_bytes / sizeof(float) - wt_floats;
 
     const int st = g->stride;
     IGemmParams cls[4];

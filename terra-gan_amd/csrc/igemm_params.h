@@ -25,6 +25,11 @@ struct IGemmParams {
     const float* gate;      // optional [dst pixels][N]: result *= act'(gate) (fused activation backward)
     int gate_act;
     float gate_slope;
+    // Winograd path (wino.inc): raw weights with the element strides of (output row n, contraction k, tap), and room
+    // for the transformed weights; wino_u == nullptr disables it
+    const float* w_raw;
+    long w_sn, w_sk, w_stap;
+    float* wino_u;
 };
 __device__ __forceinline__ float gate_factor(const IGemmParams& p, size_t idx) {
     const float gv = p.gate[idx];

@@ -1,0 +1,101 @@
+"""Winograd F(2x2,3x3) path of the stride-1 3x3 convolutions (fwd and dgrad) against PyTorch-CPU fp32/fp64 convolution:
+ragged tile edges, masks, bias/ratio/activation epilogue, fused activation-backward gate, accumulate, split-K."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from tg_hip import lib
+    lib.load()
+    return torch.device("cuda:0")
+
+
+# B, H, W, Cin, Cout, pad
+CASES = [
+    (2, 32, 32, 64, 64, 1),
+    (1, 40, 24, 8, 64, 1),        # ragged: 40 = 2.5 tiles, 24 = 1.5 tiles; one 8-channel K step
+    (3, 17, 19, 24, 128, 1),      # odd sizes: the last Winograd tile is half outside
+    (2, 16, 16, 1024, 128, 1),    # long K -> split-K slabs
+    (1, 64, 48, 192, 64, 1),
+    (2, 20, 20, 16, 64, 0),       # pad 0: output 18x18
+    (1, 18, 22, 16, 64, 2),       # pad 2: output 20x24
+]
+
+
+def _ref_conv(x, w, bias, pad, mask, ratio, act):
+    xin = x * mask[..., None] if mask is not None else x
+    y = F.conv2d(xin.permute(0, 3, 1, 2).double(), w.double(), bias.double(), 1, pad).permute(0, 2, 3, 1)
+    if ratio is not None:
+        y = y * ratio[..., None].double()
+    if act == "relu":
+        y = y.clamp_min(0)
+    return y
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_wino_fwd(dev, case):
+    from tg_hip import ops as O
+    B, H, W, Cin, Cout, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    mask = (torch.rand(B, H, W, generator=g) > 0.3).float()
+    wd = w.contiguous(memory_format=torch.channels_last).to(dev)
+    for use_mask, act in [(False, None), (True, "relu")]:
+        m = mask if use_mask else None
+        ratio = None
+        if use_mask:
+            _, ratio_d = O.mask_update(mask.to(dev), 3, 1, pad)
+            ratio = ratio_d.cpu()
+        ref = _ref_conv(x, w, bias, pad, m, ratio, act)
+        y = O.conv_fwd(x.to(dev), wd, bias.to(dev), 3, 1, pad, in_mask=m.to(dev) if use_mask else None,
+                       ratio=ratio_d if use_mask else None, act=O.ACT_RELU if act else O.ACT_NONE)
+        err = (y.cpu().double() - ref).abs().max().item()
+        assert err <= 2e-6 * max(1.0, ref.abs().max().item()) * (Cin / 64) ** 0.5 + 3e-6, (case, use_mask, err)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_wino_dgrad(dev, case):
+    from tg_hip import ops as O
+    B, H, W, Cin, Cout, pad = case
+    if Cin % 64:                   # dgrad's output channels are Cin: the Winograd path needs a multiple of 64
+        Cin, Cout = Cout, Cin if Cin % 8 == 0 else 8
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    dy = torch.randn(B, Ho, Wo, Cout, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cout ** 0.5))
+    mask = (torch.rand(B, H, W, generator=g) > 0.3).float()
+    xact = torch.randn(B, H, W, Cin, generator=g)
+    wd = w.contiguous(memory_format=torch.channels_last).to(dev)
+    ref = F.conv_transpose2d(dy.permute(0, 3, 1, 2).double(), w.double(), None, 1, pad).permute(0, 2, 3, 1)
+    dx = O.conv_dgrad(dy.to(dev), wd, (B, H, W, Cin), 3, 1, pad)
+    tol = 2e-6 * max(1.0, ref.abs().max().item()) * (Cout / 64) ** 0.5 + 3e-6
+    assert (dx.cpu().double() - ref).abs().max().item() <= tol, case
+    # masked + accumulate
+    base = torch.randn(B, H, W, Cin, generator=g)
+    out = base.clone().to(dev)
+    O.conv_dgrad(dy.to(dev), wd, (B, H, W, Cin), 3, 1, pad, in_mask=mask.to(dev), out=out)
+    ref2 = base.double() + ref * mask[..., None].double()
+    assert (out.cpu().double() - ref2).abs().max().item() <= tol, case
+    # fused LeakyReLU backward gate
+    dxg = O.conv_dgrad(dy.to(dev), wd, (B, H, W, Cin), 3, 1, pad, gate=xact.to(dev), gate_act=O.ACT_LEAKY, gate_slope=0.2)
+    ref3 = ref * torch.where(xact > 0, 1.0, 0.2).double()
+    assert (dxg.cpu().double() - ref3).abs().max().item() <= tol, case
+
+
+def test_wino_is_deterministic(dev):
+    from tg_hip import ops as O
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 64, 64, 256, generator=g).to(dev)
+    w = (torch.randn(128, 256, 3, 3, generator=g) * 0.02).contiguous(memory_format=torch.channels_last).to(dev)
+    b = torch.zeros(128).to(dev)
+    y1 = O.conv_fwd(x, w, b, 3, 1, 1)
+    y2 = O.conv_fwd(x, w, b, 3, 1, 1)
+    assert torch.equal(y1, y2)

@@ -6,7 +6,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", f) for f in ("igemm.hip", "pointwise.hip", "smallconv.hip")]
-HDR = [os.path.join(HERE, "csrc", "common.h"), os.path.join(HERE, "csrc", "igemm_params.h"), os.path.join(ROOT, "include", "terragan_hip.h")]
+# every header / include file under csrc/ is a dependency of every object (a stale .so on the GPU box is worse than a rebuild)
+HDR = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".h", ".inc"))) + \
+    [os.path.join(ROOT, "include", "terragan_hip.h")]
 LIB = os.path.join(HERE, "lib", "libterragan_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

@@ -19,6 +19,7 @@ def dev():
 # B, H, W, Cin, Cout, pad
 CASES = [
     (2, 32, 32, 64, 64, 1),
+    (2, 32, 48, 16, 32, 1),       # one 32-channel N tile
     (1, 40, 24, 8, 64, 1),        # ragged: 40 = 2.5 tiles, 24 = 1.5 tiles; one 8-channel K step
     (3, 17, 19, 24, 128, 1),      # odd sizes: the last Winograd tile is half outside
     (2, 16, 16, 1024, 128, 1),    # long K -> split-K slabs

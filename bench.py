@@ -11,7 +11,7 @@ A "step" is one pass of mvp_gan.src.train.train_step over one batch that is alre
 
 Rank 0 prints ONE JSON line.  `value` = tiles processed by all ranks / max-over-ranks wall time of exactly K
 steps (barrier + synchronize on both sides).  `roofline` is measured live: an extra instrumented pass after the
-timed region brackets every launch of the dominant kernel (the fp32-MFMA implicit-GEMM conv) with hipEvents on
+timed region brackets every launch of the dominant kernel (the fp32-MFMA Winograd conv) with hipEvents on
 its launch stream (tg_prof_*), achieved = sum of algorithmic FLOPs / sum of kernel time.  `cpu_baseline` times
 the CPU oracle (oracle/terragan_oracle.py, "port") on the host cores, rank 0 at N=1 only.
 """
@@ -176,24 +176,29 @@ def main():
             ms = sum(float(r["ms"]) for r in sel)
             return ms, len(sel), sum(float(r["gflop"]) for r in sel) * 1e9, sum(float(r["alg_mb"]) for r in sel) * 1e6
 
-        # dominant kernel symbol = pgemm_kernel<8,16,2,2,2,2,7> (patch-staged implicit GEMM, 128x128 tile): cfg 1128
-        ms, n, fl, by = agg(lambda r: r["kind"] == "0" and r["cfg"] == "1128")
+        # dominant kernel symbol = wino_kernel (Winograd F(2x2,3x3) on the fp32 MFMA: every stride-1 3x3 conv fwd/dgrad):
+        # cfg 4064.  `achieved` follows the contract: ALGORITHMIC flops (2*M*N*K of the direct convolution)
+        # per launch / launch duration -- the kernel executes 2.25x fewer multiplies than that, so `frac` can exceed the
+        # share of the MFMA pipe that is busy, which is reported next to it as `mfma_pipe_frac` (= achieved / 2.25 / peak).
+        ms, n, fl, by = agg(lambda r: r["kind"] == "0" and r["cfg"] == "4064")
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tpath):       # offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
             tj = json.load(open(tpath))
-            key = [k for k in tj if "pgemm_kernel<8, 16" in k]
+            key = [k for k in tj if k.startswith("wino_kernel")]
             traffic = round(tj[key[0]]["hbm_bytes_per_launch"]) if key else None
-        roofline = {"bound": "mfma", "kernel": "pgemm_kernel<8,16,2,2,2,2,7> (fp32-MFMA patch-staged implicit-GEMM conv fwd/dgrad, 128x128 tile)",
+        roofline = {"bound": "mfma", "kernel": "wino_kernel (Winograd F(2x2,3x3) fp32-MFMA conv fwd/dgrad, 16x16 px x 64 ch tile)",
                     "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "mfma_pipe_frac": round(ach / 2.25 / PEAK_FP32_MFMA_TFLOPS, 4),
                     "launches_per_step": n // nprobe, "avg_launch_ms": round(ms / max(n, 1), 4),
                     "gflop_per_launch": round(fl / max(n, 1) / 1e9, 3), "alg_bytes_per_launch": round(by / max(n, 1)),
                     "kernel_ms_per_step": round(ms / nprobe, 3)}
         extra = {}
         for name, pred in [("all_conv_fwd_dgrad_mfma", lambda r: r["kind"] == "0"),
-                           ("pgemm_256x64_tile", lambda r: r["kind"] == "0" and r["cfg"] == "1064"),
+                           ("direct_pgemm_128x128_tile", lambda r: r["kind"] == "0" and r["cfg"] == "1128"),
+                           ("direct_pgemm_256x64_tile", lambda r: r["kind"] == "0" and r["cfg"] == "1064"),
                            ("wgrad_mfma", lambda r: r["kind"] == "1"),
                            ("one_channel_convs_hbm", lambda r: r["kind"] == "2"),
                            ("pgemm_bf16_operands", lambda r: r["kind"] == "3")]:

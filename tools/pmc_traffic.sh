@@ -1,0 +1,32 @@
+#!/bin/bash
+# HBM traffic per kernel launch of bench.py's step (run on the GPU box): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+# SEPARATE passes (MI355X_MICROARCH.md, HBM section), bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 on gfx950.
+# usage: tools/pmc_traffic.sh <out.json>
+set -e
+out=$1
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+mkdir -p $R/gpurun_out/pmc_traffic
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d $R/gpurun_out/pmc_traffic/$c -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $R/gpurun_out/pmc_traffic/$c.log 2>&1
+done
+python3 - "$R/gpurun_out/pmc_traffic" "$R/$out" <<'PY'
+import csv, glob, json, sys, collections
+root, out = sys.argv[1], sys.argv[2]
+acc = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"{root}/{c}/**/*counter_collection.csv", recursive=True)[0]
+    tot, n = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != c: continue
+        k = r["Kernel_Name"].split("(")[0]
+        tot[k] += float(r["Counter_Value"]); n[k] += 1
+    acc[c] = (tot, n)
+res = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts half of wide coalesced reads, MI355X_MICROARCH.md HBM section)"}
+ft, fn = acc["FETCH_SIZE"]; wt, wn = acc["WRITE_SIZE"]
+for k in sorted(ft, key=lambda k: -(2 * ft[k] + wt.get(k, 0)))[:24]:
+    res[k] = {"launches": fn[k], "fetch_kib": ft[k], "write_kib": wt.get(k, 0.0),
+              "hbm_bytes_per_launch": (2 * ft[k] + wt.get(k, 0.0)) * 1024 / max(fn[k], 1)}
+json.dump(res, open(out, "w"), indent=1)
+for k in list(res)[1:8]: print(k[:60], res[k]["launches"], round(res[k]["hbm_bytes_per_launch"] / 1e6, 1), "MB/launch")
+PY

@@ -1675,6 +1675,10 @@ extern "C" size_t tg_conv_wgrad_ws_bytes(const TgConv* g) {
     int splits, sps, T;
     wgrad_plan(g, &splits, &sps, &T);
     size_t slabs = align_up((size_t)splits * g->Cout * g->k * g->k * g->Cin, 64);
+    {
+        size_t wf = align_up(wino_wgrad_ws_floats(g), 64);
+        if (wf > slabs) slabs = wf;
+    }
     WgradParams sp = {};
     sp.C = g->Cin; sp.Cout = g->Cout; sp.k = g->k; sp.Mpix = g->B * g->Ho * g->Wo;
     if (smallconv_wgrad_applies(sp)) {
@@ -1709,6 +1713,16 @@ extern "C" int tg_conv_wgrad(const TgConv* g, const float* x, const float* in_ma
         if (db) {
             size_t used = align_up(smallconv_wgrad_ws_floats(p), 64);
             rc = tg_colsum_launch(dy, (int64_t)p.Mpix, g->Cout, db, ws + used, s);
+            if (rc) return rc;
+        }
+        return TG_OK;
+    }
+    if (wino_wgrad_ok(g, in_mask)) {          // stride-1 3x3, 64-multiples of channels: Winograd F(3x3,2x2)
+        rc = launch_wino_wgrad(g, p, dw, ws, s);
+        if (rc) return rc;
+        if (db) {
+            float* ws2 = ws + align_up(wino_wgrad_ws_floats(g), 64);
+            rc = tg_colsum_launch(dy, (int64_t)p.Mpix, g->Cout, db, ws2, s);
             if (rc) return rc;
         }
         return TG_OK;

@@ -100,3 +100,33 @@ def test_wino_is_deterministic(dev):
     y1 = O.conv_fwd(x, w, b, 3, 1, 1)
     y2 = O.conv_fwd(x, w, b, 3, 1, 1)
     assert torch.equal(y1, y2)
+
+
+# B, H, W, Cin, Cout, pad
+WGRAD_CASES = [
+    (2, 32, 32, 64, 64, 1),
+    (1, 40, 24, 64, 128, 1),      # ragged strips: 24 = 1.5 strips of 16 pixels
+    (3, 17, 19, 128, 64, 1),      # odd sizes: half tiles at the right / bottom edge
+    (2, 20, 20, 64, 64, 0),       # pad 0
+    (1, 18, 22, 64, 64, 2),       # pad 2
+    (4, 64, 64, 192, 64, 1),      # several Cin tiles, split-K over strips
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wino_wgrad(dev, case):
+    from tg_hip import ops as O
+    B, H, W, Cin, Cout, pad = case
+    g = torch.Generator().manual_seed(sum(case) + 2)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    x = torch.randn(B, H, W, Cin, generator=g)
+    dy = torch.randn(B, Ho, Wo, Cout, generator=g)
+    w = torch.zeros(Cout, Cin, 3, 3).contiguous(memory_format=torch.channels_last).to(dev)
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Cout, Cin, 3, 3), dy.permute(0, 3, 1, 2).double(),
+                                      stride=1, padding=pad)
+    dw, db = O.conv_wgrad(x.to(dev), dy.to(dev), w, 3, 1, pad)
+    err = (dw.cpu().double() - ref).abs().max().item()
+    assert err <= 3e-6 * ref.abs().max().item() + 1e-5, (case, err, ref.abs().max().item())
+    assert torch.allclose(db.cpu().double(), dy.double().sum((0, 1, 2)), atol=1e-3, rtol=1e-5)
+    dw2, _ = O.conv_wgrad(x.to(dev), dy.to(dev), w, 3, 1, pad)
+    assert torch.equal(dw, dw2)          # deterministic split-K reduction

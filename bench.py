@@ -199,7 +199,8 @@ def main():
         for name, pred in [("all_conv_fwd_dgrad_mfma", lambda r: r["kind"] == "0"),
                            ("direct_pgemm_128x128_tile", lambda r: r["kind"] == "0" and r["cfg"] == "1128"),
                            ("direct_pgemm_256x64_tile", lambda r: r["kind"] == "0" and r["cfg"] == "1064"),
-                           ("wgrad_mfma", lambda r: r["kind"] == "1"),
+                           ("wgrad_mfma_all", lambda r: r["kind"] == "1"),
+                           ("wgrad_winograd_3x3", lambda r: r["kind"] == "1" and r["cfg"] == "4164"),
                            ("one_channel_convs_hbm", lambda r: r["kind"] == "2"),
                            ("pgemm_bf16_operands", lambda r: r["kind"] == "3")]:
             ms_, n_, fl_, by_ = agg(pred)

@@ -1,4 +1,4 @@
-"""Winograd F(2x2,3x3) path of the stride-1 3x3 convolutions (fwd and dgrad) against PyTorch-CPU fp32/fp64 convolution:
+"""Winograd paths of the stride-1 3x3 convolutions (F(2x2,3x3) fwd and dgrad, F(3x3,2x2) wgrad) against PyTorch-CPU fp64:
 ragged tile edges, masks, bias/ratio/activation epilogue, fused activation-backward gate, accumulate, split-K."""
 import numpy as np
 import pytest

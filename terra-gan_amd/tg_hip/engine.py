@@ -9,7 +9,10 @@ Reference arithmetic reproduced (paths relative to /root/reference):
   discriminator_*  mvp_gan/src/models/discriminator.py:17-26
   vgg_*            torchvision vgg16.features[:16] as used by mvp_gan/src/utils/losses.py:31-34,79-90
 """
+import os
 from types import SimpleNamespace as NS
+
+import torch
 
 from . import ops as O
 
@@ -25,6 +28,48 @@ D_LAYERS = [(0, None, None, 64, 4, 2, 1, True), (2, 3, 64, 128, 4, 2, 1, True), 
             (8, 9, 256, 512, 4, 2, 1, True), (11, None, 512, 1, 4, 1, 1, False)]
 # features[:16]: conv indices, 'M' = 2x2 max-pool; every conv is followed by ReLU
 VGG_TRUNK = [0, 2, "M", 5, 7, "M", 10, 12, 14]
+
+
+# --------------------------------------------------------------------------------------------------
+# side stream for weight gradients
+# --------------------------------------------------------------------------------------------------
+# A weight gradient is a leaf of the backward graph: nothing downstream waits for it until the optimiser, so it can go to a
+# second HIP stream and run underneath the backward chain (BN-backward reductions, activation gates, dgrad).  Measured
+# (round 1, 1x MI355X): +0.9 % only -- the Winograd wgrad workgroups own a whole CU each (141 KB LDS, 2 x 256 registers
+# per SIMD) for ~300 us, so the chain's small kernels queue behind them (rocprofv3: a 21 us BN reduction stretched to
+# 380 us) and the overlap is paid back on the critical path.  Kept as an opt-in (TG_SIDE_STREAM=1) until the wgrad grid
+# can be confined to a CU subset.  Only used with persistent gradient buffers (outputs never owned by the side stream's
+# allocator pool); inputs are pinned with record_stream so the caching allocator does not recycle them.
+_side = {}
+SIDE_WGRAD = os.environ.get("TG_SIDE_STREAM") == "1"
+
+
+def _side_stream():
+    dev = torch.cuda.current_device()
+    st = _side.get(dev)
+    if st is None:
+        st = _side[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def _wgrad(gbuf, inputs, fn):
+    """fn() launches one weight gradient.  With gradient buffers it runs on the side stream, ordered after everything
+    enqueued so far on the current stream; join_side() must be called before the gradients are consumed."""
+    if gbuf is None or not SIDE_WGRAD:
+        return fn()
+    main, side = torch.cuda.current_stream(), _side_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = fn()
+    for t in inputs:
+        if t is not None:
+            t.record_stream(side)
+    return out
+
+
+def join_side():
+    if SIDE_WGRAD and torch.cuda.current_device() in _side:
+        torch.cuda.current_stream().wait_stream(_side_stream())
 
 
 # --------------------------------------------------------------------------------------------------
@@ -52,14 +97,17 @@ def _pconv_bwd(P, c, da, grads, dx_out=None, want_dx=True, gbuf=None):
     outs = (gbuf[f"{name}.bn.weight"], gbuf[f"{name}.bn.bias"], gbuf[f"{name}.input_conv.bias"]) if gbuf is not None else None
     dyr, dgamma, dbeta, db = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU,
                                           ratio=c.ratio, outs=outs)
-    dw, _ = O.conv_wgrad(c.x, dyr, P[f"{name}.input_conv.weight"], c.k, c.s, c.p,
-                         in_mask=None if getattr(c, "premasked", False) else c.in_mask, want_bias=False,
-                         dw_out=gbuf[f"{name}.input_conv.weight"] if gbuf is not None else None)
+    # dgrad first: the weight gradient is enqueued behind it on the side stream, so it starts when the dgrad has
+    # finished and runs underneath the NEXT layer's BatchNorm-backward reductions (small grids) and its dgrad
+    dx = O.conv_dgrad(dyr, P[f"{name}.input_conv.weight"], tuple(c.x.shape), c.k, c.s, c.p, in_mask=c.in_mask, out=dx_out) \
+        if want_dx else None
+    wmask = None if getattr(c, "premasked", False) else c.in_mask
+    dw, _ = _wgrad(gbuf, (c.x, dyr, wmask), lambda: O.conv_wgrad(
+        c.x, dyr, P[f"{name}.input_conv.weight"], c.k, c.s, c.p, in_mask=wmask, want_bias=False,
+        dw_out=gbuf[f"{name}.input_conv.weight"] if gbuf is not None else None))
     grads[f"{name}.input_conv.weight"], grads[f"{name}.input_conv.bias"] = dw, db
     grads[f"{name}.bn.weight"], grads[f"{name}.bn.bias"] = dgamma, dbeta
-    if not want_dx:
-        return None
-    return O.conv_dgrad(dyr, P[f"{name}.input_conv.weight"], tuple(c.x.shape), c.k, c.s, c.p, in_mask=c.in_mask, out=dx_out)
+    return dx
 
 
 # --------------------------------------------------------------------------------------------------
@@ -126,10 +174,10 @@ def generator_backward(P, ctx, dout, want_dx=False, gbuf=None):
     dz, dx_comp = O.sigmoid_composite_bwd(dout, ctx.logits.reshape(B, H, W), ctx.mask, want_dx)
     dz = dz.reshape(B, H, W, 1)
     d0 = _act_of(P, ctx.dec[6]) if ckpt else ctx.d0
-    grads["final.weight"], grads["final.bias"] = O.conv_wgrad(
-        d0, dz, P["final.weight"], 3, 1, 1, dw_out=gbuf["final.weight"] if gbuf is not None else None,
-        db_out=gbuf["final.bias"] if gbuf is not None else None)
     da = O.conv_dgrad(dz, P["final.weight"], tuple(d0.shape), 3, 1, 1)
+    grads["final.weight"], grads["final.bias"] = _wgrad(gbuf, (d0, dz), lambda: O.conv_wgrad(
+        d0, dz, P["final.weight"], 3, 1, 1, dw_out=gbuf["final.weight"] if gbuf is not None else None,
+        db_out=gbuf["final.bias"] if gbuf is not None else None))
     del d0
     dskips = {}
     for i in range(6, -1, -1):                     # dec1 ... dec7
@@ -161,6 +209,7 @@ def generator_backward(P, ctx, dout, want_dx=False, gbuf=None):
             dx = _pconv_bwd(P, c, da, grads, want_dx=want_dx, gbuf=gbuf)
     if want_dx:
         dx = O.axpby_(dx_comp, 1.0, 1.0, dx.reshape(B, H, W))
+    join_side()
     return grads, dx
 
 
@@ -208,11 +257,6 @@ def discriminator_backward(P, ctx, dlogits, want_wgrad=True, want_dimg=False, gb
                                                  O.ACT_LEAKY, 0.2, want_dbias=want_wgrad, outs=outs)
             if want_wgrad:
                 grads[f"model.{c.bi}.weight"], grads[f"model.{c.bi}.bias"] = dgamma, dbeta
-        if want_wgrad:
-            dw, db2 = O.conv_wgrad(c.x, dy, w, c.k, c.s, c.p, want_bias=db is None,
-                                   dw_out=gbuf[f"model.{c.ci}.weight"] if gbuf is not None else None,
-                                   db_out=gbuf[f"model.{c.ci}.bias"] if (gbuf is not None and db is None) else None)
-            grads[f"model.{c.ci}.weight"], grads[f"model.{c.ci}.bias"] = dw, (db if db is not None else db2)
         gated = False
         if li > 0 or want_dimg:
             below = ctx.layers[li - 1] if li > 0 else None
@@ -223,6 +267,13 @@ def discriminator_backward(P, ctx, dlogits, want_wgrad=True, want_dimg=False, gb
                 da = O.conv_dgrad(dy, w, tuple(c.x.shape), c.k, c.s, c.p)
         else:
             da = None
+        if want_wgrad:       # behind the dgrad, see _pconv_bwd
+            dw, db2 = _wgrad(gbuf, (c.x, dy), lambda c=c, dy=dy, w=w, db=db: O.conv_wgrad(
+                c.x, dy, w, c.k, c.s, c.p, want_bias=db is None,
+                dw_out=gbuf[f"model.{c.ci}.weight"] if gbuf is not None else None,
+                db_out=gbuf[f"model.{c.ci}.bias"] if (gbuf is not None and db is None) else None))
+            grads[f"model.{c.ci}.weight"], grads[f"model.{c.ci}.bias"] = dw, (db if db is not None else db2)
+    join_side()
     return grads, da
 
 

@@ -156,10 +156,25 @@ __device__ __forceinline__ bool final_reduce(const float* __restrict__ partial, 
     double acc[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) acc[i] = 0.0;
-    if (c < C)
-        for (int b = rl; b < nblocks; b += FR_LANES)
+    if (c < C) {
+        // 4 partial rows per trip: the loads of a trip are independent, so their latencies overlap (a rolled loop with
+        // the fp64 add in it exposed one L2 round trip per row and made this tiny kernel cost ~10 us)
+        int b = rl;
+        for (; b + 3 * FR_LANES < nblocks; b += 4 * FR_LANES) {
+            float v[4][NQ];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) v[u][i] = partial[((size_t)(b + u * FR_LANES) * NQ + i) * C + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) acc[i] += (double)v[u][i];
+        }
+        for (; b < nblocks; b += FR_LANES)
 #pragma unroll
             for (int i = 0; i < NQ; ++i) acc[i] += (double)partial[((size_t)b * NQ + i) * C + c];
+    }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) fr[i][rl][col] = acc[i];
     __syncthreads();
@@ -987,10 +1002,15 @@ __global__ __launch_bounds__(256) void pixel_loss_sums_kernel(const float* __res
 __global__ void pixel_loss_final_kernel(const double* __restrict__ partial, int nblocks, int B, int H, int W, float w_l1,
                                         float w_tv, float w_bnd, float eps, const float* __restrict__ gscale,
                                         float* __restrict__ out5, float* __restrict__ coef) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one wave: lane l sums blocks l, l+64, ... in order, then a fixed xor tree over the lanes -> deterministic
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
     double s[5] = {0, 0, 0, 0, 0};
-    for (int b = 0; b < nblocks; ++b)
+    for (int b = threadIdx.x; b < nblocks; b += 64)
+#pragma unroll
         for (int i = 0; i < 5; ++i) s[i] += partial[(size_t)b * 5 + i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) s[i] = wave_sum_d(s[i]);
+    if (threadIdx.x != 0) return;
     const double n = (double)B * H * W;
     const double count_h = (double)B * (H - 1) * W, count_w = (double)B * H * (W - 1);
     const float l1 = (float)(s[0] / n);
@@ -1078,10 +1098,11 @@ __global__ __launch_bounds__(256) void l1_mean_kernel(const float* __restrict__ 
     block_reduce_store<1>(q, partial);
 }
 __global__ void mean_final_kernel(const double* __restrict__ partial, int nblocks, double inv_n, float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
     double s = 0;
-    for (int b = 0; b < nblocks; ++b) s += partial[b];
-    out[0] = (float)(s * inv_n);
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[b];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) out[0] = (float)(s * inv_n);
 }
 extern "C" int tg_l1_mean(const float* a, const float* b, int64_t n, float coef, const float* gscale, float* out1, float* da,
                           float* ws, size_t ws_bytes, tg_stream_t stream) {

@@ -1,5 +1,7 @@
 // Micro-benchmark: issue rate of v_mfma_f32_32x32x2_f32 per SIMD as a function of waves/SIMD and accumulators per wave.
-// hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_rate.hip -o /tmp/mfma_rate && /tmp/mfma_rate
+// hipcc -O3 -w --offload-arch=gfx950 tools/micro/mfma_rate.hip -o tools/micro/mfma_rate && tools/micro/mfma_rate
+// Result (MI355X): one wave per SIMD already issues at the full rate (148-156 TFLOP/s), with 1..16 accumulators, random
+// operands and 141 KB of LDS allocated alike -- MFMA issue is never the limit of the Winograd kernels by itself.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -130,3 +130,31 @@ def test_wino_wgrad(dev, case):
     assert torch.allclose(db.cpu().double(), dy.double().sum((0, 1, 2)), atol=1e-3, rtol=1e-5)
     dw2, _ = O.conv_wgrad(x.to(dev), dy.to(dev), w, 3, 1, pad)
     assert torch.equal(dw, dw2)          # deterministic split-K reduction
+
+
+def test_winograd_kernels_are_the_ones_that_run(dev, tmp_path):
+    """Eligible stride-1 3x3 layers must go through wino_kernel (launch tag 4064) / wino_wgrad_kernel (4164): a silent
+    fall-back to the direct kernels would keep every parity test green and lose the speed."""
+    import csv
+    import ctypes as C
+    from tg_hip import lib as L
+    from tg_hip import ops as O
+    lib = L.load()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 32, 32, 64, generator=g).to(dev)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).contiguous(memory_format=torch.channels_last).to(dev)
+    b = torch.zeros(64).to(dev)
+    for kind in (0, 1, 2, 3):          # drop records of earlier tests
+        lib.tg_prof_summary(kind, None, None, None, None)
+    lib.tg_prof_enable(1)
+    y = O.conv_fwd(x, w, b, 3, 1, 1)
+    O.conv_dgrad(y, w, tuple(x.shape), 3, 1, 1)
+    O.conv_wgrad(x, y, w, 3, 1, 1)
+    torch.cuda.synchronize()
+    lib.tg_prof_enable(0)
+    path = str(tmp_path / "launches.csv")
+    assert lib.tg_prof_dump(path.encode()) == 0
+    tags = [(r["kind"], r["cfg"]) for r in csv.DictReader(open(path))]
+    for kind in (0, 1, 2, 3):
+        lib.tg_prof_summary(kind, None, None, None, None)
+    assert tags.count(("0", "4064")) == 2 and ("1", "4164") in tags, tags

@@ -55,6 +55,15 @@ struct ProfScope {
     }
 };
 
+// algorithmic-FLOP scale of the launches issued on behalf of a rewritten problem (5x5 stride-2 layers run as 3x3 over a
+// space-to-depth input: 25 of its 36 taps are real work), so that the profile tags count the ORIGINAL convolution
+static thread_local double g_alg_scale = 1.0;
+struct AlgScale {
+    double prev;
+    explicit AlgScale(double sc) : prev(g_alg_scale) { g_alg_scale = sc; }
+    ~AlgScale() { g_alg_scale = prev; }
+};
+
 extern "C" int tg_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
@@ -1001,6 +1010,81 @@ static size_t conv_wino_floats(const TgConv* g) {
     return align_up(wino_u_floats(g->Cout, g->Cin), 64);
 }
 
+// ---- 5x5 stride-2 layers on the Winograd kernels ---------------------------------------------------
+// A 5x5 / stride 2 / pad 2 convolution is EXACTLY a 3x3 / stride 1 / pad 1 convolution over the space-to-depth input
+// x2[b][yy][xx][(dy,dx,c)] = x[b][2yy+dy][2xx+dx][c] with weights w2[co][ty][tx][(dy,dx,c)] = w[co][2ty+dy][2tx+dx][c]
+// (taps with 2ty+dy = 5 or 2tx+dx = 5 are zero: 25 of 36 live).  1.44x the algorithmic work, but on the Winograd kernels
+// (2.25x fewer multiplies, twice the rate of the strided gather kernels) enc2 / enc3 come out ~35 % faster, forward,
+// dgrad and wgrad alike.  The rearrangements are one bandwidth-bound pass each; the mask multiply of the partial conv
+// rides in the space-to-depth pass, so the Winograd kernels see a pre-masked input.
+__global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ x2,
+                                                  int B, int H, int W, int C) {
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)B * H * W * C4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(idx % C4);
+        int64_t pix = idx / C4;
+        const int xw = (int)(pix % W);
+        int64_t t = pix / W;
+        const int yh = (int)(t % H);
+        const int b = (int)(t / H);
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * C + 4 * c4);
+        if (mask) v *= mask[pix];
+        const int64_t p2 = ((int64_t)b * (H >> 1) + (yh >> 1)) * (W >> 1) + (xw >> 1);
+        *reinterpret_cast<f32x4*>(x2 + p2 * (4 * C) + ((yh & 1) * 2 + (xw & 1)) * C + 4 * c4) = v;
+    }
+}
+// dx[b][y][x][c] (+)= dx2[b][y/2][x/2][(y&1, x&1, c)] * mask
+__global__ __launch_bounds__(256) void d2s_kernel(const float* __restrict__ dx2, const float* __restrict__ mask, float* __restrict__ dx,
+                                                  int B, int H, int W, int C, int accumulate) {
+    const int C4 = C >> 2;
+    const int64_t total = (int64_t)B * H * W * C4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(idx % C4);
+        int64_t pix = idx / C4;
+        const int xw = (int)(pix % W);
+        int64_t t = pix / W;
+        const int yh = (int)(t % H);
+        const int b = (int)(t / H);
+        const int64_t p2 = ((int64_t)b * (H >> 1) + (yh >> 1)) * (W >> 1) + (xw >> 1);
+        f32x4 v = *reinterpret_cast<const f32x4*>(dx2 + p2 * (4 * C) + ((yh & 1) * 2 + (xw & 1)) * C + 4 * c4);
+        if (mask) v *= mask[pix];
+        float* o = dx + pix * C + 4 * c4;
+        if (accumulate) v += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = v;
+    }
+}
+// to3 = 1: w2[co][ty][tx][(dy,dx,c)] = w[co][2ty+dy][2tx+dx][c] (0 where that tap does not exist);  to3 = 0: the inverse gather
+__global__ __launch_bounds__(256) void w5x5_s2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int C, int to3) {
+    const int64_t total = to3 ? (int64_t)Cout * 36 * C : (int64_t)Cout * 25 * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        int64_t t = idx / C;
+        if (to3) {
+            const int ph = (int)(t % 4), tap = (int)((t / 4) % 9), co = (int)(t / 36);
+            const int ky = 2 * (tap / 3) + (ph >> 1), kx = 2 * (tap % 3) + (ph & 1);
+            dst[idx] = (ky < 5 && kx < 5) ? src[((int64_t)co * 25 + ky * 5 + kx) * C + c] : 0.f;
+        } else {
+            const int k = (int)(t % 25), co = (int)(t / 25);
+            const int ky = k / 5, kx = k % 5;
+            dst[idx] = src[(((int64_t)co * 9 + (ky >> 1) * 3 + (kx >> 1)) * 4 + (ky & 1) * 2 + (kx & 1)) * C + c];
+        }
+    }
+}
+static bool s2d_ok(const TgConv* g) {
+    static const bool off = getenv("TG_NO_WINO") != nullptr || getenv("TG_NO_S2D") != nullptr;
+    if (off || g->precision == TG_PREC_BF16) return false;
+    return g->k == 5 && g->stride == 2 && g->pad == 2 && (g->H % 2) == 0 && (g->W % 2) == 0 && (g->Cin % 16) == 0 &&
+           (g->Cout % 64) == 0 && g->Ho >= 32 && g->Wo >= 32 && g->Ho == g->H / 2 && g->Wo == g->W / 2;   // smaller: not worth 3 extra passes
+}
+static TgConv s2d_geom(const TgConv* g) {
+    TgConv g2 = *g;
+    g2.H = g->H / 2; g2.W = g->W / 2; g2.Cin = 4 * g->Cin; g2.k = 3; g2.stride = 1; g2.pad = 1;
+    return g2;
+}
+static size_t s2d_x_floats(const TgConv* g) { return align_up((size_t)g->B * g->H * g->W * g->Cin, 64); }
+static size_t s2d_w_floats(const TgConv* g) { return align_up((size_t)g->Cout * 36 * g->Cin, 64); }
+
 // ---- forward ----------------------------------------------------------------------------------
 extern "C" size_t tg_conv_fwd_ws_bytes(const TgConv* g) {
     if (!g) return 0;
@@ -1008,7 +1092,12 @@ extern "C" size_t tg_conv_fwd_ws_bytes(const TgConv* g) {
     size_t out = (size_t)g->B * g->Ho * g->Wo * g->Cout;
     size_t cap = (size_t)64 << 20;  // floats
     size_t want = out * 16;
-    return ((want < cap ? want : cap) + conv_wino_floats(g)) * sizeof(float);
+    size_t base = ((want < cap ? want : cap) + conv_wino_floats(g)) * sizeof(float);
+    if (s2d_ok(g)) {
+        const TgConv g2 = s2d_geom(g);
+        base = (s2d_x_floats(g) + s2d_w_floats(g)) * sizeof(float) + tg_conv_fwd_ws_bytes(&g2);
+    }
+    return base;
 }
 
 extern "C" int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* bias,
@@ -1018,6 +1107,22 @@ extern "C" int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask
     if (rc) return rc;
     TG_REQUIRE(x && w && y, "tg_conv_fwd: null pointer");
     TG_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), "tg_conv_fwd: pointers must be 16-byte aligned");
+    if (s2d_ok(g) && ws && aligned16(ws) && ws_bytes >= tg_conv_fwd_ws_bytes(g)) {
+        // 5x5 stride 2 -> 3x3 stride 1 over the space-to-depth input (see s2d_kernel)
+        hipStream_t s = (hipStream_t)stream;
+        const TgConv g2 = s2d_geom(g);
+        float* x2 = ws;
+        float* w2 = ws + s2d_x_floats(g);
+        float* ws2 = w2 + s2d_w_floats(g);
+        hipLaunchKernelGGL(s2d_kernel, dim3(ew_grid((int64_t)g->B * g->H * g->W * (g->Cin / 4), 256)), dim3(256), 0, s, x, in_mask, x2,
+                           g->B, g->H, g->W, g->Cin);
+        TG_CHECK_LAUNCH("s2d_kernel");
+        hipLaunchKernelGGL(w5x5_s2d_kernel, dim3(ew_grid((int64_t)g->Cout * 36 * g->Cin, 256)), dim3(256), 0, s, w, w2, g->Cout, g->Cin, 1);
+        TG_CHECK_LAUNCH("w5x5_s2d_kernel");
+        AlgScale sc(25.0 / 36.0);
+        return tg_conv_fwd(&g2, x2, nullptr, w2, bias, ratio, act, slope, y, ws2,
+                           ws_bytes - (s2d_x_floats(g) + s2d_w_floats(g)) * sizeof(float), stream);
+    }
     IGemmParams p = {};
     p.src = x; p.amask = in_mask; p.wmat = w; p.bias = bias; p.rowscale = ratio; p.dst = y; p.ws = ws;
     p.B = g->B; p.IH = g->H; p.IW = g->W; p.C = g->Cin;
@@ -1072,6 +1177,10 @@ extern "C" size_t tg_conv_dgrad_ws_bytes(const TgConv* g) {
     size_t out = (size_t)g->B * g->H * g->W * g->Cin;
     size_t cap = (size_t)64 << 20;
     size_t want = out * 16;
+    if (s2d_ok(g)) {
+        const TgConv g2 = s2d_geom(g);
+        return (s2d_x_floats(g) + s2d_w_floats(g)) * sizeof(float) + tg_conv_dgrad_ws_bytes(&g2);
+    }
     return (wt + (want < cap ? want : cap)) * sizeof(float);
 }
 
@@ -1092,6 +1201,26 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, con
     if (rc) return rc;
     TG_REQUIRE(dy && w && dx && ws, "tg_conv_dgrad: null pointer");
     TG_REQUIRE(aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(ws), "tg_conv_dgrad: pointers must be 16-byte aligned");
+    if (s2d_ok(g) && gate == nullptr && ws_bytes >= tg_conv_dgrad_ws_bytes(g)) {
+        // dx2 = 3x3 stride-1 dgrad over the space-to-depth layout, then depth-to-space (+ mask, + accumulate)
+        hipStream_t s2 = (hipStream_t)stream;
+        const TgConv g2 = s2d_geom(g);
+        float* dx2 = ws;
+        float* w2 = ws + s2d_x_floats(g);
+        float* wsr = w2 + s2d_w_floats(g);
+        hipLaunchKernelGGL(w5x5_s2d_kernel, dim3(ew_grid((int64_t)g->Cout * 36 * g->Cin, 256)), dim3(256), 0, s2, w, w2, g->Cout, g->Cin, 1);
+        TG_CHECK_LAUNCH("w5x5_s2d_kernel");
+        {
+            AlgScale sc(25.0 / 36.0);
+            rc = conv_dgrad_impl(&g2, dy, w2, nullptr, dx2, 0, nullptr, 0, 0.f, wsr,
+                                 ws_bytes - (s2d_x_floats(g) + s2d_w_floats(g)) * sizeof(float), stream);
+        }
+        if (rc) return rc;
+        hipLaunchKernelGGL(d2s_kernel, dim3(ew_grid((int64_t)g->B * g->H * g->W * (g->Cin / 4), 256)), dim3(256), 0, s2, dx2, in_mask, dx,
+                           g->B, g->H, g->W, g->Cin, accumulate);
+        TG_CHECK_LAUNCH("d2s_kernel");
+        return TG_OK;
+    }
     const int taps = g->k * g->k;
     const size_t wt_floats = dgrad_wt_floats(g);
     TG_REQUIRE(ws_bytes >= wt_floats * sizeof(float), "tg_conv_dgrad: workspace too small (%zu < %zu)", ws_bytes,
@@ -1679,6 +1808,11 @@ extern "C" size_t tg_conv_wgrad_ws_bytes(const TgConv* g) {
         size_t wf = align_up(wino_wgrad_ws_floats(g), 64);
         if (wf > slabs) slabs = wf;
     }
+    if (s2d_ok(g)) {
+        const TgConv g2 = s2d_geom(g);
+        size_t wf = s2d_x_floats(g) + s2d_w_floats(g) + align_up(wino_wgrad_ws_floats(&g2), 64);
+        if (wino_wgrad_ok(&g2, nullptr) && wf > slabs) slabs = wf;
+    }
     WgradParams sp = {};
     sp.C = g->Cin; sp.Cout = g->Cout; sp.k = g->k; sp.Mpix = g->B * g->Ho * g->Wo;
     if (smallconv_wgrad_applies(sp)) {
@@ -1716,6 +1850,35 @@ extern "C" int tg_conv_wgrad(const TgConv* g, const float* x, const float* in_ma
             if (rc) return rc;
         }
         return TG_OK;
+    }
+    if (s2d_ok(g)) {
+        const TgConv g2 = s2d_geom(g);
+        if (wino_wgrad_ok(&g2, nullptr)) {
+            // 5x5 stride 2: Winograd wgrad over the (masked) space-to-depth input, then gather the 25 live taps
+            float* x2 = ws;
+            float* dw2 = ws + s2d_x_floats(g);
+            float* wsr = dw2 + s2d_w_floats(g);
+            hipLaunchKernelGGL(s2d_kernel, dim3(ew_grid((int64_t)g->B * g->H * g->W * (g->Cin / 4), 256)), dim3(256), 0, s, x, in_mask,
+                               x2, g->B, g->H, g->W, g->Cin);
+            TG_CHECK_LAUNCH("s2d_kernel");
+            WgradParams p2 = p;
+            p2.x = x2; p2.amask = nullptr; p2.H = g2.H; p2.W = g2.W; p2.C = g2.Cin; p2.k = 3; p2.stride = 1; p2.pad = 1;
+            p2.Ktot = 9 * g2.Cin;
+            {
+                AlgScale sc(25.0 / 36.0);
+                rc = launch_wino_wgrad(&g2, p2, dw2, wsr, s);
+            }
+            if (rc) return rc;
+            hipLaunchKernelGGL(w5x5_s2d_kernel, dim3(ew_grid((int64_t)g->Cout * 25 * g->Cin, 256)), dim3(256), 0, s, dw2, dw, g->Cout,
+                               g->Cin, 0);
+            TG_CHECK_LAUNCH("w5x5_s2d_kernel");
+            if (db) {
+                float* ws2 = wsr + align_up(wino_wgrad_ws_floats(&g2), 64);
+                rc = tg_colsum_launch(dy, (int64_t)p.Mpix, g->Cout, db, ws2, s);
+                if (rc) return rc;
+            }
+            return TG_OK;
+        }
     }
     if (wino_wgrad_ok(g, in_mask)) {          // stride-1 3x3, 64-multiples of channels: Winograd F(3x3,2x2)
         rc = launch_wino_wgrad(g, p, dw, ws, s);

@@ -158,3 +158,37 @@ def test_winograd_kernels_are_the_ones_that_run(dev, tmp_path):
     for kind in (0, 1, 2, 3):
         lib.tg_prof_summary(kind, None, None, None, None)
     assert tags.count(("0", "4064")) == 2 and ("1", "4164") in tags, tags
+
+
+# 5x5 / stride 2 / pad 2 layers (enc2, enc3) run as a 3x3 stride-1 Winograd convolution over the space-to-depth input
+S2D_CASES = [(2, 64, 64, 64, 128), (1, 64, 96, 16, 64), (2, 64, 64, 128, 256)]   # B, H, W, Cin, Cout
+
+
+@pytest.mark.parametrize("case", S2D_CASES)
+def test_s2d_5x5_stride2(dev, case):
+    from tg_hip import ops as O
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case) + 3)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 5, 5, generator=g) / (5 * Cin ** 0.5)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    mask = (torch.rand(B, H, W, generator=g) > 0.3).float()
+    wd = w.contiguous(memory_format=torch.channels_last).to(dev)
+    mo, ratio_d = O.mask_update(mask.to(dev), 5, 2, 2)
+    xm = (x * mask[..., None]).permute(0, 3, 1, 2).double()
+    ref = F.conv2d(xm, w.double(), bias.double(), 2, 2).permute(0, 2, 3, 1) * ratio_d.cpu()[..., None].double()
+    y = O.conv_fwd(x.to(dev), wd, bias.to(dev), 5, 2, 2, in_mask=mask.to(dev), ratio=ratio_d)
+    tol = 3e-6 * max(1.0, ref.abs().max().item()) * (Cin / 16) ** 0.5 + 3e-6
+    assert (y.cpu().double() - ref).abs().max().item() <= tol, case
+    # dgrad (masked, accumulate) and wgrad (masked input)
+    dy = torch.randn(B, H // 2, W // 2, Cout, generator=g)
+    refdx = F.conv_transpose2d(dy.permute(0, 3, 1, 2).double(), w.double(), None, 2, 2, output_padding=1).permute(0, 2, 3, 1)
+    base = torch.randn(B, H, W, Cin, generator=g)
+    out = base.clone().to(dev)
+    O.conv_dgrad(dy.to(dev), wd, (B, H, W, Cin), 5, 2, 2, in_mask=mask.to(dev), out=out)
+    ref2 = base.double() + refdx * mask[..., None].double()
+    assert (out.cpu().double() - ref2).abs().max().item() <= 3e-6 * max(1.0, refdx.abs().max().item()) * (Cout / 16) ** 0.5 + 3e-6, case
+    refdw = torch.nn.grad.conv2d_weight(xm, (Cout, Cin, 5, 5), dy.permute(0, 3, 1, 2).double(), stride=2, padding=2)
+    dw, db = O.conv_wgrad(x.to(dev), dy.to(dev), wd, 5, 2, 2, in_mask=mask.to(dev))
+    assert (dw.cpu().double() - refdw).abs().max().item() <= 3e-6 * refdw.abs().max().item() + 1e-5, case
+    assert torch.allclose(db.cpu().double(), dy.double().sum((0, 1, 2)), atol=1e-3, rtol=1e-5)

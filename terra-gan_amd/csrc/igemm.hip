@@ -922,7 +922,7 @@ static bool try_pgemm(IGemmParams* ps, int ncls, size_t ws_floats_avail, hipStre
             while (smax > 1 && (size_t)smax * p.M * p.N > ws_floats_avail) --smax;
             splits = choose_splits(work, smax, 512);
         }
-    } else if (work < 384) {
+    } else if (work < 256) {
         return false;           // merged launch has no split-K: too small a grid goes class by class instead
     }
     q.chunks_per_split = cdiv(p.nchunks, splits);

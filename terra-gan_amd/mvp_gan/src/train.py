@@ -112,7 +112,19 @@ def train_step(generator, discriminator, criterion, optimizer_G, optimizer_D, re
     gen, gctx = E.generator_forward(GP, masked, mask, generator.training,
                                     checkpoint=getattr(generator, "activation_checkpointing", False))     # train.py:185
     g_loss, _parts, dgen = criterion_forward(criterion, gen, real, mask, want_grad=True)   # train.py:188
-    fake_logits, dctx_fake = E.discriminator_forward(DP, gen, discriminator.training)      # train.py:202
+    # D(fake) of this step (train.py:202), D(real) and D(fake.detach()) of the discriminator step (train.py:211-212) see the
+    # same discriminator weights, and D(real) depends on nothing the generator step produces: the two distinct passes are
+    # stacked along the batch and run as ONE grouped forward (convolutions once over 2B images, BatchNorm statistics per
+    # pass), and the discriminator step's two backward passes as one.  Running statistics are replayed in the
+    # reference's order fake, real, fake.
+    grouped = reuse_fake_forward and discriminator.training
+    if grouped:
+        logits2, dctx2 = E.discriminator_forward(DP, torch.cat([gen, real]), True, groups=2, update_running=False)
+        E.discriminator_replay_running_stats(DP, dctx2, order=(0,))          # train.py:202
+        fake_logits, real_logits = logits2[:B], logits2[B:]
+        dctx_fake = E.discriminator_group(dctx2, 0)
+    else:
+        fake_logits, dctx_fake = E.discriminator_forward(DP, gen, discriminator.training)  # train.py:202
     g_adv, dlogits = O.bce_logits(fake_logits, 1.0)                          # train.py:203
     g_total = O.lincomb(g_loss, 1.0, g_adv, 1.0)                             # train.py:204
     _none, dgen_adv = E.discriminator_backward(DP, dctx_fake, dlogits, want_wgrad=False, want_dimg=True)
@@ -129,19 +141,23 @@ def train_step(generator, discriminator, criterion, optimizer_G, optimizer_D, re
 
     # ---- discriminator ----------------------------------------------------------------------------
     optimizer_D.zero_grad()                                                  # train.py:210
-    real_logits, dctx_real = E.discriminator_forward(DP, real, discriminator.training)     # train.py:211
-    if reuse_fake_forward and discriminator.training:
-        E.discriminator_replay_running_stats(DP, dctx_fake)                  # train.py:212 (identical pass)
+    if grouped:
+        E.discriminator_replay_running_stats(DP, dctx2, order=(1, 0))        # train.py:211, 212
     else:
-        fake_logits, dctx_fake = E.discriminator_forward(DP, gen, discriminator.training)
+        real_logits, dctx_real = E.discriminator_forward(DP, real, discriminator.training)     # train.py:211
+        fake_logits, dctx_fake = E.discriminator_forward(DP, gen, discriminator.training)      # train.py:212
     real_loss, dl_real = O.bce_logits(real_logits, 1.0, coef=0.5)            # train.py:215,217
     fake_loss, dl_fake = O.bce_logits(fake_logits, 0.0, coef=0.5)            # train.py:216,217
     d_loss = O.lincomb(real_loss, 0.5, fake_loss, 0.5)
-    dg_real, _ = E.discriminator_backward(DP, dctx_real, dl_real, want_wgrad=True,
-                                          gbuf=grad_buffers(discriminator).views)          # train.py:218
-    dg_fake, _ = E.discriminator_backward(DP, dctx_fake, dl_fake, want_wgrad=True)
-    for k, g in dg_real.items():
-        O.axpby_(dg_fake[k], 1.0, 1.0, g)
+    if grouped:
+        dg_real, _ = E.discriminator_backward(DP, dctx2, torch.cat([dl_fake, dl_real]), want_wgrad=True,
+                                              gbuf=grad_buffers(discriminator).views)      # train.py:218
+    else:
+        dg_real, _ = E.discriminator_backward(DP, dctx_real, dl_real, want_wgrad=True,
+                                              gbuf=grad_buffers(discriminator).views)      # train.py:218
+        dg_fake, _ = E.discriminator_backward(DP, dctx_fake, dl_fake, want_wgrad=True)
+        for k, g in dg_real.items():
+            O.axpby_(dg_fake[k], 1.0, 1.0, g)
     _assign_grads(discriminator, dg_real)
     if grad_sync is not None:
         db = grad_sync(discriminator, "D")

@@ -216,9 +216,16 @@ def generator_backward(P, ctx, dout, want_dx=False, gbuf=None):
 # --------------------------------------------------------------------------------------------------
 # discriminator
 # --------------------------------------------------------------------------------------------------
-def discriminator_forward(P, img, training=True):
-    """img [B][H][W] (1 channel) or [B][H][W][C].  Returns (logits [B][h][w][1], ctx)."""
+def discriminator_forward(P, img, training=True, groups=1, update_running=True):
+    """img [B][H][W] (1 channel) or [B][H][W][C].  Returns (logits [B][h][w][1], ctx).
+
+    groups > 1: the batch is `groups` independent passes stacked along B (train_step stacks D(fake) and D(real),
+    which share weights: train.py:202,211): convolutions run once over the whole stack, BatchNorm statistics are taken per
+    group exactly as the separate passes would.  update_running=False leaves the running statistics alone (the caller
+    replays the updates in the reference's order with discriminator_replay_running_stats)."""
     h = img if img.dim() == 4 else img.reshape(*img.shape, 1)
+    Bg = h.shape[0] // groups
+    assert Bg * groups == h.shape[0]
     layers = []
     for (ci, bi, _cin, _cout, k, s, p, leaky) in D_LAYERS:
         w, b = P[f"model.{ci}.weight"], P[f"model.{ci}.bias"].detach()
@@ -228,15 +235,37 @@ def discriminator_forward(P, img, training=True):
             layers.append(NS(ci=ci, bi=None, k=k, s=s, p=p, x=h, a=a, act=act))
         else:
             y = O.conv_fwd(h, w, b, k, s, p)
-            if training:
-                mean, rstd = O.bn_stats(y, P[f"model.{bi}.running_mean"], P[f"model.{bi}.running_var"],
-                                        P[f"model.{bi}.num_batches_tracked"])
-            else:
-                mean, rstd = O.bn_eval_stats(P[f"model.{bi}.running_mean"], P[f"model.{bi}.running_var"])
-            a = O.bn_act_fwd(y, mean, rstd, P[f"model.{bi}.weight"], P[f"model.{bi}.bias"], O.ACT_LEAKY, 0.2)
-            layers.append(NS(ci=ci, bi=bi, k=k, s=s, p=p, x=h, y=y, mean=mean, rstd=rstd, a=a))
+            a = torch.empty_like(y)
+            means, rstds = [], []
+            for gi in range(groups):
+                yg, ag = y[gi * Bg:(gi + 1) * Bg], a[gi * Bg:(gi + 1) * Bg]
+                if training:
+                    run = (P[f"model.{bi}.running_mean"], P[f"model.{bi}.running_var"], P[f"model.{bi}.num_batches_tracked"]) \
+                        if update_running else (None, None, None)
+                    mean, rstd = O.bn_stats(yg, *run)
+                else:
+                    mean, rstd = O.bn_eval_stats(P[f"model.{bi}.running_mean"], P[f"model.{bi}.running_var"])
+                O.bn_act_fwd(yg, mean, rstd, P[f"model.{bi}.weight"], P[f"model.{bi}.bias"], O.ACT_LEAKY, 0.2, out=ag)
+                means.append(mean), rstds.append(rstd)
+            layers.append(NS(ci=ci, bi=bi, k=k, s=s, p=p, x=h, y=y, mean=means[0], rstd=rstds[0], means=means, rstds=rstds, a=a))
         h = a
-    return h, NS(layers=layers)
+    return h, NS(layers=layers, groups=groups)
+
+
+def discriminator_group(ctx, gi):
+    """The context of pass `gi` of a grouped forward, as views (what a separate forward of that pass would have kept)."""
+    G = ctx.groups
+    out = []
+    for c in ctx.layers:
+        Bg = c.x.shape[0] // G
+        sl = slice(gi * Bg, (gi + 1) * Bg)
+        d = dict(vars(c))
+        d["x"], d["a"] = c.x[sl], c.a[sl]
+        if c.bi is not None:
+            d["y"], d["mean"], d["rstd"] = c.y[sl], c.means[gi], c.rstds[gi]
+            d["means"], d["rstds"] = [c.means[gi]], [c.rstds[gi]]
+        out.append(NS(**d))
+    return NS(layers=out, groups=1)
 
 
 def discriminator_backward(P, ctx, dlogits, want_wgrad=True, want_dimg=False, gbuf=None):
@@ -253,8 +282,23 @@ def discriminator_backward(P, ctx, dlogits, want_wgrad=True, want_dimg=False, gb
         else:
             outs = (gbuf[f"model.{c.bi}.weight"], gbuf[f"model.{c.bi}.bias"], gbuf[f"model.{c.ci}.bias"]) \
                 if (gbuf is not None and want_wgrad) else None
-            dy, dgamma, dbeta, db = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"model.{c.bi}.weight"], P[f"model.{c.bi}.bias"],
-                                                 O.ACT_LEAKY, 0.2, want_dbias=want_wgrad, outs=outs)
+            G_ = getattr(ctx, "groups", 1)
+            if G_ == 1:
+                dy, dgamma, dbeta, db = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"model.{c.bi}.weight"], P[f"model.{c.bi}.bias"],
+                                                     O.ACT_LEAKY, 0.2, want_dbias=want_wgrad, outs=outs)
+            else:
+                # BatchNorm backward per pass (its batch sums belong to one pass); the parameter gradients add up
+                Bg = da.shape[0] // G_
+                dy = da
+                for gi in range(G_):
+                    sl = slice(gi * Bg, (gi + 1) * Bg)
+                    _d, g1, b1, db1 = O.bn_act_bwd(da[sl], c.y[sl], c.means[gi], c.rstds[gi], P[f"model.{c.bi}.weight"],
+                                                   P[f"model.{c.bi}.bias"], O.ACT_LEAKY, 0.2, want_dbias=want_wgrad,
+                                                   outs=outs if gi == 0 else None)
+                    if gi == 0:
+                        dgamma, dbeta, db = g1, b1, db1
+                    elif want_wgrad:
+                        O.axpby_(g1, 1.0, 1.0, dgamma), O.axpby_(b1, 1.0, 1.0, dbeta), O.axpby_(db1, 1.0, 1.0, db)
             if want_wgrad:
                 grads[f"model.{c.bi}.weight"], grads[f"model.{c.bi}.bias"] = dgamma, dbeta
         gated = False
@@ -277,14 +321,18 @@ def discriminator_backward(P, ctx, dlogits, want_wgrad=True, want_dimg=False, gb
     return grads, da
 
 
-def discriminator_replay_running_stats(P, ctx):
-    """Re-apply the BN running-stat update of a forward pass whose inputs and weights are identical
-    to `ctx`'s (D(gen.detach()) after D(gen), train.py:202,212) without recomputing it."""
+def discriminator_replay_running_stats(P, ctx, order=(0,)):
+    """Apply the BN running-stat updates of forward passes whose batch statistics `ctx` holds, in `order` (group indices):
+    D(gen.detach()) after D(gen) repeats a pass (train.py:202,212), and a grouped forward leaves all updates to this
+    function so that they happen in the reference's order."""
+    G_ = getattr(ctx, "groups", 1)
     for c in ctx.layers:
         if c.bi is not None:
-            rows = c.y.numel() // c.y.shape[-1]
-            O.bn_running_update(c.mean, c.rstd, rows, P[f"model.{c.bi}.running_mean"], P[f"model.{c.bi}.running_var"],
-                                P[f"model.{c.bi}.num_batches_tracked"])
+            rows = c.y.numel() // c.y.shape[-1] // G_
+            for gi in order:
+                mean, rstd = (c.means[gi], c.rstds[gi]) if hasattr(c, "means") else (c.mean, c.rstd)
+                O.bn_running_update(mean, rstd, rows, P[f"model.{c.bi}.running_mean"], P[f"model.{c.bi}.running_var"],
+                                    P[f"model.{c.bi}.num_batches_tracked"])
 
 
 # --------------------------------------------------------------------------------------------------

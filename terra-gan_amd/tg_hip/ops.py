@@ -194,10 +194,11 @@ def bn_running_update(mean, rstd, rows, running_mean, running_var, nbt, eps=BN_E
                                         _p(running_var), nbt_p, _stream()), "tg_bn_running_update")
 
 
-def bn_act_fwd(y, mean, rstd, gamma, beta, act, slope=0.0):
-    _chk(y, "y")
+def bn_act_fwd(y, mean, rstd, gamma, beta, act, slope=0.0, out=None):
+    _chk(y, "y"); _chk(out, "out")
     Cc = y.shape[-1]
-    out = torch.empty_like(y)
+    if out is None:
+        out = torch.empty_like(y)
     L.check(_lib().tg_bn_act_fwd(_p(y), y.numel() // Cc, Cc, _p(mean), _p(rstd), _p(gamma.detach()), _p(beta.detach()), act,
                                  slope, _p(out), _stream()), "tg_bn_act_fwd")
     return out

@@ -132,7 +132,9 @@ def test_step_matches_module_autograd(dev):
     real, mask = Orc.synth_batch(2, 128, 5)
     real, mask = real.to(dev), mask.to(dev)
     G1, D1, crit, oG1, oD1 = _build(dev)
-    out = train_step(G1, D1, crit, oG1, oD1, real, mask)
+    # reuse_fake_forward=False: the schedule with three separate discriminator passes, launch for launch what autograd runs
+    # (the default grouped schedule sums the weight gradients in another order: test_grouped_discriminator_passes)
+    out = train_step(G1, D1, crit, oG1, oD1, real, mask, reuse_fake_forward=False)
     G2, D2, crit2, oG2, oD2 = _build(dev)
     bce = lambda z, t: _BCE.apply(z, t)
     oG2.zero_grad()
@@ -149,6 +151,33 @@ def test_step_matches_module_autograd(dev):
     for (k, a), (_k, b_) in zip(list(G1.state_dict().items()) + list(D1.state_dict().items()),
                                 list(G2.state_dict().items()) + list(D2.state_dict().items())):
         assert torch.allclose(a.float(), b_.float(), atol=1e-6, rtol=1e-5), k
+
+
+def test_grouped_discriminator_passes(dev):
+    """Default train_step stacks D(fake) and D(real) into one grouped forward and the discriminator step's two backward
+    passes into one (convolutions over 2B images, BatchNorm per pass).  Against the three-separate-passes schedule:
+    identical losses, generator gradients and BatchNorm running statistics; discriminator gradients equal up to the fp32
+    summation order of the weight-gradient reductions."""
+    from mvp_gan.src.train import train_step
+    from oracle import terragan_oracle as Orc
+    real, mask = Orc.synth_batch(4, 128, 6)
+    real, mask = real.to(dev), mask.to(dev)
+    res = []
+    for grouped in (True, False):
+        G, D, crit, oG, oD = _build(dev)
+        out = train_step(G, D, crit, oG, oD, real, mask, reuse_fake_forward=grouped)
+        res.append((G, D, {k: float(v) for k, v in out.items() if k != "gen"}))
+    (Ga, Da, la), (Gb, Db, lb) = res
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-6 * abs(lb[k]) + 1e-9, (k, la[k], lb[k])
+    for (k, a), (_k, b_) in zip(Ga.named_parameters(), Gb.named_parameters()):
+        if a.grad is not None:
+            assert torch.equal(a.grad, b_.grad), k
+    for (k, a), (_k, b_) in zip(Da.named_parameters(), Db.named_parameters()):
+        ga, gb_ = a.grad.double(), b_.grad.double()
+        assert (ga - gb_).abs().max().item() <= 2e-5 * gb_.abs().max().item() + 1e-9, k
+    for (k, a), (_k, b_) in zip(Da.named_buffers(), Db.named_buffers()):
+        assert torch.allclose(a.double(), b_.double(), rtol=1e-6, atol=1e-8), k
 
 
 class _BCE(torch.autograd.Function):

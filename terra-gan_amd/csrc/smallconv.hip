@@ -315,18 +315,26 @@ __global__ __launch_bounds__(256) void to1wgrad64_kernel(const WgradParams p, fl
     }
 }
 
-// second stage of the small wgrad kernels: 4 lanes share one output element and split the partial blocks (fixed order)
+// second stage of the small wgrad kernels: ONE WAVE per output element -- lane l sums partial blocks l, l+64, ... (four
+// independent loads per trip), then a fixed xor tree over the lanes: deterministic, and the ~1000 partials of an element
+// are no longer a serial chain of dependent loads (that cost 74 us for 576 outputs)
 __global__ __launch_bounds__(256) void smallconv_slab_reduce(const float* __restrict__ ws, float* __restrict__ out, size_t n,
                                                              int splits) {
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t idx = gid >> 2;
-    const int part = (int)(gid & 3);
+    const size_t idx = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     double v = 0.0;
-    if (idx < n)
-        for (int z = part; z < splits; z += 4) v += (double)ws[(size_t)z * n + idx];
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    if (idx < n && part == 0) out[idx] = (float)v;
+    if (idx < n) {
+        int z = lane;
+        for (; z + 192 < splits; z += 256) {
+            const float a0 = ws[(size_t)z * n + idx], a1 = ws[(size_t)(z + 64) * n + idx];
+            const float a2 = ws[(size_t)(z + 128) * n + idx], a3 = ws[(size_t)(z + 192) * n + idx];
+            v += (double)a0 + (double)a1 + (double)a2 + (double)a3;
+        }
+        for (; z < splits; z += 64) v += (double)ws[(size_t)z * n + idx];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (idx < n && lane == 0) out[idx] = (float)v;
 }
 
 static int to1_wgrad_blocks(const WgradParams& p) {
@@ -378,7 +386,7 @@ int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream
         TG_CHECK_LAUNCH("to1wgrad64_kernel");
     }
     const size_t n = (size_t)p.Cout * p.k * p.k * p.C;
-    hipLaunchKernelGGL(smallconv_slab_reduce, dim3((unsigned)cdiv64((int64_t)n * 4, 256)), dim3(256), 0, s, ws, dw, n, nb);
+    hipLaunchKernelGGL(smallconv_slab_reduce, dim3((unsigned)cdiv64((int64_t)n, 4)), dim3(256), 0, s, ws, dw, n, nb);
     TG_CHECK_LAUNCH("smallconv_slab_reduce");
     return TG_OK;
 }

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- DSM tiles/sec through one full GAN train step (G + D + losses + Adam).
 
-Workload = BASELINE.json configs[1]: 256x256 1-channel synthetic DSM tiles + random disc masks, batch 16
+Default workload = BASELINE.json configs[1]: 256x256 1-channel synthetic DSM tiles + random disc masks, batch 16
 PER GPU, fp32, partial-conv U-Net generator + PatchGAN discriminator + L1/perceptual/TV/boundary losses.
 A "step" is one pass of mvp_gan.src.train.train_step over one batch that is already resident in HBM.
+Other BASELINE configs: --size 512 --batch 8 --precision bf16 (configs[2]); --size 1024 --batch 4 --checkpoint
+(configs[4] per GPU); `metric` and `config.workload` are derived from the arguments.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -14,6 +16,14 @@ steps (barrier + synchronize on both sides).  `roofline` is measured live: an ex
 timed region brackets every launch of the dominant kernel (the fp32-MFMA Winograd conv) with hipEvents on
 its launch stream (tg_prof_*), achieved = sum of algorithmic FLOPs / sum of kernel time.  `cpu_baseline` times
 the CPU oracle (oracle/terragan_oracle.py, "port") on the host cores, rank 0 at N=1 only.
+
+Roofline fields (every one can be recomputed from profiles/*_conv_launches.csv + *_kernel_stats.csv):
+  achieved          EXECUTED MFMA TFLOP/s of the dominant kernel = algorithmic FLOPs / 2.25 / kernel time (Winograd
+                    F(2x2,3x3) issues 16 multiplies where the direct convolution has 36)
+  frac              achieved / 157.3 TF (fp32-MFMA dense peak) -- the share of the matrix pipe that is busy, <= 1
+  effective_tflops  algorithmic (direct-convolution) FLOPs / kernel time -- what the layer would need on a direct kernel
+  layers            per-layer lines for the full-resolution PConv layers the 40 %-of-HBM target is about (enc1, dec1,
+                    dec2, final): alg_GBps / frac_hbm against 8 TB/s next to tflops / frac_mfma of the same launches
 """
 import argparse
 import ctypes as C
@@ -31,6 +41,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: bf16 MFMA dense (not the 2:1-sparsity headline)
 PEAK_HBM_GBS = 8000.0
 TILE = 256
 BATCH = 16
@@ -42,24 +53,43 @@ def prof_summary(lib, kind):
     return ms.value, n.value, fl.value, by.value
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """CPU oracle train step on the host cores: bounded sample of the same workload (batch 4, 256x256)."""
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(size=TILE, batch=BATCH, seconds_budget=30.0):
+    """CPU oracle train step on the host cores, bounded sample of the SAME workload: the bench's own batch size and tile
+    size (B=16 at 256x256; B=1 = configs[0] is timed beside it), 1 warm-up step, then whole steps
+    until ~seconds_budget is used (at least 1, at most 5)."""
     from oracle import terragan_oracle as Orc
     # the GPU box gives a 1-GPU job a 16-core CPU share although os.cpu_count() reports the whole host
     torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
-    st = Orc.TrainState(0)
-    b = 4
-    real, mask = Orc.synth_batch(b, TILE, 1000)
-    Orc.train_step(st, real, mask)                      # warm-up (oneDNN primitive creation)
-    t0, n = time.perf_counter(), 0
-    while True:
-        Orc.train_step(st, real, mask)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget * 0.5 or n >= 4:
-            break
-    return {"value": round(b * n / el, 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} train steps of the CPU oracle at batch {b}, 256x256 fp32, after 1 warm-up step ({el:.1f} s)"}
+
+    def timed(b, budget, max_steps):
+        st = Orc.TrainState(0)
+        real, mask = Orc.synth_batch(b, size, 1000)
+        Orc.train_step(st, real, mask)                  # warm-up (oneDNN primitive creation)
+        t0, n = time.perf_counter(), 0
+        while True:
+            Orc.train_step(st, real, mask)
+            n += 1
+            el = time.perf_counter() - t0
+            if n >= max_steps or el * (n + 1) / n > budget:
+                break
+        return n, el
+
+    n, el = timed(batch, seconds_budget * 0.8, 5)
+    n1, el1 = timed(1, seconds_budget * 0.2, 5)
+    return {"value": round(batch * n / el, 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": _cpu_model(), "b1_value": round(n1 / el1, 3),
+            "sample": f"{n} train steps of the CPU oracle at batch {batch}, {size}x{size} fp32, after 1 warm-up step "
+                      f"({el:.1f} s); b1_value = {n1} steps at batch 1 (BASELINE configs[0], {el1:.1f} s)"}
 
 
 def main():
@@ -77,6 +107,8 @@ def main():
     ap.add_argument("--prof-dump", default=None, help="write the per-launch table of the instrumented pass to this CSV")
     args = ap.parse_args()
 
+    # before the first HIP call (torch.cuda.is_available() initialises the runtime): the host driver only supports dmabuf IPC
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -93,7 +125,6 @@ def main():
     dev = torch.device("cuda", local_rank)
     force_dp = os.environ.get("TG_FORCE_DP") == "1"        # exercise the RCCL path with a single rank (rehearsal)
     if world > 1 or force_dp:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if force_dp and world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
@@ -161,9 +192,11 @@ def main():
         nprobe = 2
         if rank == 0:
             lib.tg_prof_enable(1)
+            _O.PROF_TAGS = True
         run(nprobe)
         torch.cuda.synchronize()
         lib.tg_prof_enable(0)
+        _O.PROF_TAGS = False
     if rank == 0 and not args.no_roofline:
         dump = args.prof_dump or os.path.join(tempfile.gettempdir(), f"tg_prof_{os.getpid()}.csv")
         lib.tg_prof_dump(dump.encode())
@@ -171,29 +204,55 @@ def main():
         for kind in (0, 1, 2, 3):
             prof_summary(lib, kind)                       # consume the records
 
+        WINO = ("4064", "4164")                           # Winograd kernels execute 16/36 of the algorithmic multiplies
+
         def agg(pred):
             sel = [r for r in rows if pred(r)]
             ms = sum(float(r["ms"]) for r in sel)
-            return ms, len(sel), sum(float(r["gflop"]) for r in sel) * 1e9, sum(float(r["alg_mb"]) for r in sel) * 1e6
+            fl = sum(float(r["gflop"]) for r in sel) * 1e9
+            ex = sum(float(r["gflop"]) / (2.25 if r["cfg"] in WINO else 1.0) for r in sel) * 1e9
+            return ms, len(sel), fl, sum(float(r["alg_mb"]) for r in sel) * 1e6, ex
 
-        # dominant kernel symbol = wino_kernel (Winograd F(2x2,3x3) on the fp32 MFMA: every stride-1 3x3 conv fwd/dgrad):
-        # cfg 4064.  `achieved` follows the contract: ALGORITHMIC flops (2*M*N*K of the direct convolution)
-        # per launch / launch duration -- the kernel executes 2.25x fewer multiplies than that, so `frac` can exceed the
-        # share of the MFMA pipe that is busy, which is reported next to it as `mfma_pipe_frac` (= achieved / 2.25 / peak).
-        ms, n, fl, by = agg(lambda r: r["kind"] == "0" and r["cfg"] == "4064")
-        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):       # offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-            tj = json.load(open(tpath))
-            key = [k for k in tj if k.startswith("wino_kernel")]
-            traffic = round(tj[key[0]]["hbm_bytes_per_launch"]) if key else None
-        roofline = {"bound": "mfma", "kernel": "wino_kernel (Winograd F(2x2,3x3) fp32-MFMA conv fwd/dgrad, 16x16 px x 64 ch tile)",
-                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "mfma_pipe_frac": round(ach / 2.25 / PEAK_FP32_MFMA_TFLOPS, 4),
+        def line(pred):
+            ms_, n_, fl_, by_, ex_ = agg(pred)
+            if ms_ <= 0:
+                return None
+            sec = ms_ * 1e-3
+            mfma = all(r["kind"] != "2" for r in rows if pred(r))      # kind 2 = 1-channel-side convs: never on the MFMA
+            d = {"kernel_ms_per_step": round(ms_ / nprobe, 3), "launches_per_step": n_ // nprobe,
+                 "alg_GBps": round(by_ / sec / 1e9, 1), "frac_hbm": round(by_ / sec / 1e9 / PEAK_HBM_GBS, 4),
+                 "tflops": round(fl_ / sec / 1e12, 2)}
+            d["frac_mfma"] = round(ex_ / sec / 1e12 / peak_tf, 4) if mfma else None
+            return d
+
+        peak_tf = PEAK_FP32_MFMA_TFLOPS if args.precision == "f32" else PEAK_BF16_MFMA_TFLOPS
+        # dominant kernel: fp32 -> wino_kernel (Winograd F(2x2,3x3) on the fp32 MFMA: every stride-1 3x3 conv fwd/dgrad,
+        # cfg 4064); bf16 mode -> the bf16-operand patch GEMM (kind 3)
+        if args.precision == "f32":
+            dom, dom_name = (lambda r: r["kind"] == "0" and r["cfg"] == "4064"), \
+                "wino_kernel (Winograd F(2x2,3x3) fp32-MFMA conv fwd/dgrad, 16x16 px x 64 ch tile)"
+        else:
+            dom, dom_name = (lambda r: r["kind"] == "3"), "pgemm/igemm/wgrad bf16-operand MFMA kernels (v_mfma_f32_32x32x16_bf16)"
+        ms, n, fl, by, ex = agg(dom)
+        sec = ms * 1e-3
+        ach = ex / sec / 1e12 if ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath):   # offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+                tj = json.load(open(tpath))
+                key = [k for k in tj if k.startswith("wino_kernel")]
+                if key and args.precision == "f32" and args.size == TILE and args.batch == BATCH:
+                    traffic, traffic_src = round(tj[key[0]]["hbm_bytes_per_launch"]), "profiles/" + tname
+                break
+        roofline = {"bound": "mfma", "kernel": dom_name,
+                    "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                    "frac": round(ach / peak_tf, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "effective_tflops": round(fl / sec / 1e12, 2) if ms > 0 else 0.0,
                     "launches_per_step": n // nprobe, "avg_launch_ms": round(ms / max(n, 1), 4),
-                    "gflop_per_launch": round(fl / max(n, 1) / 1e9, 3), "alg_bytes_per_launch": round(by / max(n, 1)),
+                    "gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
+                    "executed_gflop_per_launch": round(ex / max(n, 1) / 1e9, 3),
+                    "alg_bytes_per_launch": round(by / max(n, 1)),
                     "kernel_ms_per_step": round(ms / nprobe, 3)}
         extra = {}
         for name, pred in [("all_conv_fwd_dgrad_mfma", lambda r: r["kind"] == "0"),
@@ -202,27 +261,41 @@ def main():
                            ("wgrad_mfma_all", lambda r: r["kind"] == "1"),
                            ("wgrad_winograd_3x3", lambda r: r["kind"] == "1" and r["cfg"] == "4164"),
                            ("one_channel_convs_hbm", lambda r: r["kind"] == "2"),
-                           ("pgemm_bf16_operands", lambda r: r["kind"] == "3")]:
-            ms_, n_, fl_, by_ = agg(pred)
-            if ms_ > 0:
-                extra[name] = {"kernel_ms_per_step": round(ms_ / nprobe, 3), "launches_per_step": n_ // nprobe,
-                               "TFLOPs": round(fl_ / (ms_ * 1e-3) / 1e12, 2), "alg_GBps": round(by_ / (ms_ * 1e-3) / 1e9, 1)}
+                           ("bf16_operand_kernels", lambda r: r["kind"] == "3")]:
+            d = line(pred)
+            if d is not None:
+                extra[name] = d
         roofline["other_kernels"] = extra
+        # the full-resolution partial-conv layers north_star's ">= 40 % of the memory roofline" is about, both ways
+        layers = {}
+        for lname in ("enc1", "dec1", "dec2", "final"):
+            for part in ("fwd", "dgrad", "wgrad"):
+                d = line(lambda r, t=f"{lname}.{part}": r.get("tag") == t)
+                if d is not None:
+                    layers[f"{lname}.{part}"] = d
+        roofline["layers"] = layers
     if world > 1:
         dist.barrier()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(args.size, args.batch)
 
     if rank == 0:
         tiles = args.batch * world * args.steps
-        line = {"metric": "DSM tiles/sec train-step (G+D) at 256x256 bs=16", "value": round(tiles / elapsed, 2),
+        prec_txt = "fp32" if args.precision == "f32" else "bf16 mixed precision (bf16 MFMA operands, fp32 accumulate / storage / masters)"
+        cfg_idx = {(256, 16, "f32", False): "configs[1]" if world == 1 else "configs[3] per-GPU shape",
+                   (512, 8, "bf16", False): "configs[2]",
+                   (1024, 4, "f32", True): "configs[4] per-GPU shape"}.get((args.size, args.batch, args.precision, args.checkpoint),
+                                                                           "non-BASELINE shape")
+        line = {"metric": f"DSM tiles/sec train-step (G+D) at {args.size}x{args.size} bs={args.batch}",
+                "value": round(tiles / elapsed, 2),
                 "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16 operands / f32 accumulate+storage", "data": "synthetic",
-                "config": {"workload": f"BASELINE configs[1]: {args.size}x{args.size} 1-ch DSM tiles, batch {args.batch} per GPU, "
-                                       "fp32, PConv-UNet G + PatchGAN D + L1/VGG-perceptual/TV/boundary losses + 2x Adam",
+                "config": {"workload": f"BASELINE {cfg_idx}: {args.size}x{args.size} 1-ch DSM tiles, batch {args.batch} per GPU, "
+                                       f"{prec_txt}, PConv-UNet G + PatchGAN D + L1/VGG-perceptual/TV/boundary(0.5) losses + 2x Adam"
+                                       + (", activation checkpointing" if args.checkpoint else ""),
                            "global_batch": args.batch * world, "tile": args.size,
                            "parallelism": f"dp{world}" if world > 1 else "single-gpu",
                            "vgg_weights": "deterministic stand-in (ImageNet weights not fetchable offline; same FLOPs)"},

@@ -219,14 +219,37 @@ int tg_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, tg_str
 
 /* ---- measurement hooks (bench.py roofline figures; no reference counterpart) ------------------- */
 
+/* Quality metrics the reference logs per batch / validation pass, in ONE pass over [imgs][H][W] fp32 tensors
+ * (imgs = B*C) with no host synchronisation:
+ *   out[0] mse   out[1] psnr = 20 log10(1/sqrt(mse)) (inf when mse == 0)   out[2] ssim (11x11 avg_pool2d windows, zero
+ *   padding, divisor 121, C1 = 0.01^2, C2 = 0.03^2)   out[3] l1   out[4] l2 = sqrt(mse)
+ *     -- utils/experiment_tracking.py:176-231 (= MaskEvaluator._calculate_psnr/_ssim, evaluation/metrics.py:47-76)
+ *   out[5] boundary_mse = mean over ALL elements of ((pred-target)*band)^2, band = clamp(maxpool3(m) - (1 - maxpool3(1-m)))
+ *   out[6] boundary_psnr = 10 log10(1 / (boundary_mse + 1e-6))
+ *   out[7] boundary_gradient_diff = | (mean|dy pred| + mean|dx pred|) - (mean|dy target| + mean|dx target|) |
+ *   out[8] sum(band); out[5..7] are 0 when sum(band) < 1e-6
+ *     -- calculate_boundary_quality, mvp_gan/src/evaluation/metrics.py:79-133
+ * ws: 8-byte aligned, >= tg_quality_metrics_ws_bytes(). */
+size_t tg_quality_metrics_ws_bytes(int64_t imgs, int H, int W);
+int tg_quality_metrics(const float* pred, const float* target, const float* mask, int64_t imgs, int H, int W,
+                       float* out9, float* ws, size_t ws_bytes, tg_stream_t stream);
+
+/* Pre-decoded uint8 tile shards -> fp32 tiles on the device: img_f32 = img_u8 / 255 (IEEE fp32 division),
+ * mask_f32 = mask_u8 > 0 -- mvp_gan/src/utils/dataset.py:35-37 (ToTensor scaling, binarise AFTER the resize).
+ * Either input may be NULL.  n elements; pointers 16-byte aligned. */
+int tg_u8_to_tiles(const uint8_t* img_u8, const uint8_t* mask_u8, int64_t n, float* img_f32, float* mask_f32,
+                   tg_stream_t stream);
+
 /* When enabled, every launch of the MFMA conv kernels is bracketed by hipEvents on its own launch
  * stream and tagged with its algorithmic FLOPs and bytes.  kind: 0 = fwd/dgrad implicit GEMM,
  * 1 = wgrad.  tg_prof_summary synchronises those events (host-blocking: call it outside any timed
  * region), returns the totals for `kind` and consumes its records. */
 int tg_prof_enable(int on);
 int tg_prof_summary(int kind, double* total_ms, int64_t* launches, double* flops, double* bytes);
-/* One CSV row per recorded launch (kind,cfg,M,N,K,C,splits,ms,gflop,alg_mb); records are kept. */
+/* One CSV row per recorded launch (kind,cfg,M,N,K,C,splits,ms,gflop,alg_mb,tag); records are kept. */
 int tg_prof_dump(const char* path);
+/* Label (<= 31 chars, e.g. "dec1.fwd") attached to the launches recorded after it on the calling thread. */
+int tg_prof_tag(const char* tag);
 
 #ifdef __cplusplus
 }

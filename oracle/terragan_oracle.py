@@ -415,15 +415,70 @@ def dp_train_step(st: TrainState, reals: List[Tensor], masks: List[Tensor]):
         gens.append(gen)
         scal.append(gs)
         gsum = gg if gsum is None else {k: gsum[k] + gg[k] for k in gsum}
-    st.opt_g.step({k: v / n for k, v in gsum.items()})
+    st.last_gg = {k: v / n for k, v in gsum.items()}       # the averaged gradients (what the all-reduce delivers)
+    st.opt_g.step(st.last_gg)
     dsum = None
     for r in range(n):
         dp_r = {k: v.clone() for k, v in st.dp.items()} if r else st.dp
         dg, ds = d_step_grads(dp_r, reals[r], gens[r])
         scal[r].update(ds)
         dsum = dg if dsum is None else {k: dsum[k] + dg[k] for k in dsum}
-    st.opt_d.step({k: v / n for k, v in dsum.items()})
+    st.last_dg = {k: v / n for k, v in dsum.items()}
+    st.opt_d.step(st.last_dg)
     return gens, scal
+
+
+# ----------------------------------------------------------------------------
+# validation pass and logged quality metrics (SURVEY §8f row 4)
+# ----------------------------------------------------------------------------
+@torch.no_grad()
+def validation_losses(gp: Params, dp: Params, vp: Params, real: Tensor, mask: Tensor,
+                      w_perc=0.1, w_tv=0.1, w_bnd=0.5) -> Tuple[Tensor, Tensor, Tensor]:
+    """Validation body -- train.py:283-301: generator in EVAL mode (running statistics), criterion, then D(real) and
+    D(gen) with the discriminator left in TRAIN mode (train.py:279 switches only the generator), so D's BatchNorm running
+    statistics move during validation too (SURVEY App. A #8).  Returns (val_g_total, val_d, gen)."""
+    gen = generator_forward(gp, real * mask, mask, False)
+    g_total, _ = inpainting_loss(vp, gen, real, mask, w_perc, w_tv, w_bnd)
+    d_real = bce_logits(discriminator_forward(dp, real, True), 1.0)
+    d_fake = bce_logits(discriminator_forward(dp, gen, True), 0.0)
+    return g_total, 0.5 * (d_real + d_fake), gen
+
+
+def boundary_quality(pred: Tensor, target: Tensor, mask: Tensor) -> Dict[str, float]:
+    """calculate_boundary_quality -- mvp_gan/src/evaluation/metrics.py:79-133.  The MSE is a mean over ALL elements of
+    ((pred-target)*band)^2 (:101), not over the band; `boundary_width` is unused there."""
+    band = boundary_band(mask)                                                  # :88-90
+    if float(band.sum()) < 1e-6:                                                # :93-98
+        return {"boundary_mse": 0.0, "boundary_psnr": 0.0, "boundary_gradient_diff": 0.0}
+    mse = (((pred - target) * band) ** 2).mean()                                # :101
+    psnr = 10 * torch.log10(1.0 / (mse + 1e-6))                                 # :104-106
+    pd = (pred[:, :, 1:, :] - pred[:, :, :-1, :]).abs().mean() + (pred[:, :, :, 1:] - pred[:, :, :, :-1]).abs().mean()
+    td = (target[:, :, 1:, :] - target[:, :, :-1, :]).abs().mean() + (target[:, :, :, 1:] - target[:, :, :, :-1]).abs().mean()
+    return {"boundary_mse": float(mse), "boundary_psnr": float(psnr), "boundary_gradient_diff": float((pd - td).abs())}
+
+
+def psnr(pred: Tensor, target: Tensor) -> float:
+    """utils/experiment_tracking.py:196-206 (= MaskEvaluator._calculate_psnr, evaluation/metrics.py:47-54)."""
+    mse = F.mse_loss(pred, target)
+    if float(mse) == 0:
+        return float("inf")
+    return float(20 * torch.log10(1.0 / torch.sqrt(mse)))
+
+
+def ssim(pred: Tensor, target: Tensor, window: int = 11) -> float:
+    """utils/experiment_tracking.py:209-231: box-window SSIM, avg_pool2d with zero padding (divisor window^2)."""
+    c1, c2, pad = 0.01 ** 2, 0.03 ** 2, window // 2
+    mu1, mu2 = F.avg_pool2d(pred, window, 1, pad), F.avg_pool2d(target, window, 1, pad)
+    s1 = F.avg_pool2d(pred * pred, window, 1, pad) - mu1 * mu1
+    s2 = F.avg_pool2d(target * target, window, 1, pad) - mu2 * mu2
+    s12 = F.avg_pool2d(pred * target, window, 1, pad) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s1 + s2 + c2))
+    return float(m.mean())
+
+
+def l1_l2(pred: Tensor, target: Tensor) -> Tuple[float, float]:
+    """utils/experiment_tracking.py:176-192."""
+    return float((pred - target).abs().mean()), float(F.mse_loss(pred, target).sqrt())
 
 
 # ----------------------------------------------------------------------------

@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", f) for f in ("igemm.hip", "pointwise.hip", "smallconv.hip")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("igemm.hip", "pointwise.hip", "smallconv.hip", "metrics.hip")]
 # every header / include file under csrc/ is a dependency of every object (a stale .so on the GPU box is worse than a rebuild)
 HDR = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".h", ".inc"))) + \
     [os.path.join(ROOT, "include", "terragan_hip.h")]

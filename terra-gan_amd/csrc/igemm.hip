@@ -11,6 +11,7 @@
 // MFMA number e of a k-group consumes element e of that fetch on both operands, i.e. k = 8g+4h+e
 // for lane half h -- a permutation of the k order, which a sum over k does not care about.
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <vector>
@@ -27,10 +28,12 @@ struct ProfRec {
     int kind;  // 0 = igemm (fwd/dgrad), 1 = wgrad
     double flops, bytes;
     int M, N, K, C, splits, cfg;
+    char tag[32];
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
+static thread_local char g_prof_tag[32] = "";      // layer label of the launches that follow (tg_prof_tag)
 
 struct ProfScope {
     bool on = false;
@@ -43,6 +46,7 @@ struct ProfScope {
         on = true;
         r.kind = kind; r.flops = flops; r.bytes = bytes;
         r.M = M; r.N = N; r.K = K; r.C = C; r.splits = splits; r.cfg = cfg;
+        memcpy(r.tag, g_prof_tag, sizeof(r.tag));
         (void)hipEventCreate(&r.a);
         (void)hipEventCreate(&r.b);
         (void)hipEventRecord(r.a, s);
@@ -69,18 +73,24 @@ extern "C" int tg_prof_enable(int on) {
     g_prof_on = on != 0;
     return TG_OK;
 }
-// Writes one CSV row per recorded launch (kind,cfg,M,N,K,C,splits,ms,gflop,alg_mb) without consuming the records.
+// Labels the profiled launches that follow on this thread (e.g. "dec1.fwd"); bench.py's per-layer roofline lines use it.
+extern "C" int tg_prof_tag(const char* tag) {
+    strncpy(g_prof_tag, tag ? tag : "", sizeof(g_prof_tag) - 1);
+    g_prof_tag[sizeof(g_prof_tag) - 1] = 0;
+    return TG_OK;
+}
+// Writes one CSV row per recorded launch (kind,cfg,M,N,K,C,splits,ms,gflop,alg_mb,tag) without consuming the records.
 extern "C" int tg_prof_dump(const char* path) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     FILE* f = fopen(path, "w");
     if (!f) { tg_set_error("tg_prof_dump: cannot open %s", path); return TG_ERR_ARG; }
-    fprintf(f, "kind,cfg,M,N,K,C,splits,ms,gflop,alg_mb\n");
+    fprintf(f, "kind,cfg,M,N,K,C,splits,ms,gflop,alg_mb,tag\n");
     for (auto& r : g_prof) {
         (void)hipEventSynchronize(r.b);
         float t = 0.f;
         (void)hipEventElapsedTime(&t, r.a, r.b);
-        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.5f,%.4f,%.3f\n", r.kind, r.cfg, r.M, r.N, r.K, r.C, r.splits, t, r.flops / 1e9,
-                r.bytes / 1e6);
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.5f,%.4f,%.3f,%s\n", r.kind, r.cfg, r.M, r.N, r.K, r.C, r.splits, t, r.flops / 1e9,
+                r.bytes / 1e6, r.tag);
     }
     fclose(f);
     return TG_OK;

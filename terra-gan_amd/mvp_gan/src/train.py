@@ -20,7 +20,10 @@ Differences from the reference, none of which changes a result:
     tensors (state-dict compatible);
   * no blanket try/except around the batch (train.py:178,268-270): errors raise.
 Data parallelism: pass `grad_sync` (see tg_hip.dist.GradSync) to all-reduce G and D gradients
-over RCCL before each Adam step.
+over RCCL before each Adam step.  `train(..., grad_sync=...)` then also (i) broadcasts rank 0's parameters,
+buffers and optimiser state before the first step, (ii) gives every rank its own shard of the dataset
+(tg_hip.dist.ShardSampler, one shared permutation per epoch), (iii) writes checkpoints and tracker
+records on rank 0 only.  BatchNorm statistics stay per rank (no SyncBN in the reference); rank 0's are saved.
 """
 import logging
 import time
@@ -39,6 +42,8 @@ from .models._common import as_bhw, require_hip
 from .models.discriminator import Discriminator
 from .models.generator import PConvUNet
 from .utils.dataset import InpaintingDataset, resize_to_tensor
+from .utils.shard_dataset import ShardLoader, is_shard
+from .evaluation.metrics import calculate_boundary_quality
 from .utils.losses import HumanGuidedLoss, InpaintingLoss, criterion_forward  # noqa: F401
 
 logger = logging.getLogger(__name__)
@@ -64,6 +69,8 @@ def hip_adam_step(optimizer, grad_scale=1.0, buckets=None):
         for p in group["params"]:
             hyper[p] = (float(group["lr"]), group["betas"][0], group["betas"][1], float(group["eps"]))
 
+    layout_ok = optimizer.__dict__.setdefault("_tg_layout_ok", set())     # (p, m, v) triples already checked
+
     def _update(plist):
         """One multi-tensor launch per (hyper-parameter set, step count) group -- normally a single group."""
         groups = {}
@@ -75,6 +82,21 @@ def hip_adam_step(optimizer, grad_scale=1.0, buckets=None):
                 st["step"] = torch.tensor(0.0, dtype=torch.float32)
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            elif (p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) not in layout_ok:
+                # a state loaded from a reference-format checkpoint (main_pipeline.py:260-263) keeps the SAVED strides --
+                # contiguous OIHW -- while the parameters here are stored channels_last: re-lay the moments once to the
+                # parameter's physical layout (the kernel walks plain memory)
+                for mk in ("exp_avg", "exp_avg_sq"):
+                    t = st[mk]
+                    if t.shape != p.shape:
+                        raise ValueError(f"hip_adam_step: optimizer state {mk} has shape {tuple(t.shape)}, parameter {tuple(p.shape)}")
+                    if t.device != p.device or t.dtype != p.dtype or not (O._dense_layouts(t) & O._dense_layouts(p)):
+                        new = torch.empty_like(p, memory_format=torch.preserve_format)
+                        new.copy_(t)
+                        st[mk] = new
+                if not torch.is_tensor(st["step"]):
+                    st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
+                layout_ok.add((p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()))
             st["step"] += 1
             groups.setdefault(hyper[p] + (int(st["step"]),), []).append((p, st))
         for (lr, b1, b2, eps, step), items in groups.items():
@@ -202,12 +224,25 @@ def train(img_dir: Path, mask_dir: Path, generator: Optional[PConvUNet] = None,
         config = _default_config()
     tcfg = config["training"]
     transform = resize_to_tensor(img_size)                                   # train.py:67-70
-    train_loader = DataLoader(InpaintingDataset(img_dir, mask_dir, transform=transform),
-                              batch_size=tcfg.get("batch_size", 2), shuffle=True, num_workers=0)
+    from tg_hip.dist import ShardSampler, broadcast_state, rank_world
+    rank, world = rank_world(getattr(grad_sync, "group", None)) if grad_sync is not None else (0, 1)
+    bs = tcfg.get("batch_size", 2)
+    if is_shard(str(img_dir)):
+        # pre-decoded uint8 shard (utils/shard_dataset.py): `img_dir` is the shard directory, `mask_dir` is ignored;
+        # /255 and the mask binarisation run on the device, bit-identical to the PNG path below
+        train_loader = ShardLoader(str(img_dir), bs, shuffle=True, device=device)
+        sampler = ShardSampler(train_loader.n, rank, world, shuffle=True, seed=int(tcfg.get("seed", 0))) if world > 1 else None
+        train_loader.sampler = sampler
+    else:
+        train_set = InpaintingDataset(img_dir, mask_dir, transform=transform)
+        sampler = ShardSampler(len(train_set), rank, world, shuffle=True, seed=int(tcfg.get("seed", 0))) if world > 1 else None
+        train_loader = DataLoader(train_set, batch_size=bs, shuffle=sampler is None, sampler=sampler, num_workers=0)
     val_loader = None
-    if val_img_dir is not None and val_mask_dir is not None:
+    if val_img_dir is not None and is_shard(str(val_img_dir)):
+        val_loader = ShardLoader(str(val_img_dir), bs, shuffle=False, device=device)
+    elif val_img_dir is not None and val_mask_dir is not None:
         val_loader = DataLoader(InpaintingDataset(val_img_dir, val_mask_dir, transform=transform),
-                                batch_size=tcfg.get("batch_size", 2), shuffle=False, num_workers=0)
+                                batch_size=bs, shuffle=False, num_workers=0)
     if generator is None:
         generator = PConvUNet().to(device)
     if discriminator is None:
@@ -218,6 +253,10 @@ def train(img_dir: Path, mask_dir: Path, generator: Optional[PConvUNet] = None,
         optimizer_G = torch.optim.Adam(generator.parameters(), lr=tcfg.get("learning_rate", 2e-4))
     if optimizer_D is None:
         optimizer_D = torch.optim.Adam(discriminator.parameters(), lr=tcfg.get("learning_rate", 2e-4))
+    if world > 1:
+        broadcast_state((generator, discriminator), (optimizer_G, optimizer_D), group=getattr(grad_sync, "group", None))
+        if rank != 0:                    # checkpoints and tracker records come from rank 0 only
+            checkpoint_path, experiment_tracker = None, None
     if experiment_tracker is not None and hasattr(experiment_tracker, "_log_model_architecture"):
         experiment_tracker._log_model_architecture(generator)
 
@@ -231,6 +270,8 @@ def train(img_dir: Path, mask_dir: Path, generator: Optional[PConvUNet] = None,
         keys = ["g_loss", "d_loss", "real_loss", "fake_loss"]
         sums = {k: torch.zeros(1, device=device) for k in keys}          # device-side running sums
         epoch_start = time.time()
+        if sampler is not None:
+            sampler.set_epoch(epoch)
         for batch_idx, data in enumerate(train_loader):
             real = data["image"].to(device, non_blocking=True)
             masks = data["mask"].to(device, non_blocking=True)
@@ -239,8 +280,11 @@ def train(img_dir: Path, mask_dir: Path, generator: Optional[PConvUNet] = None,
                 O.axpby_(out[src], 1.0, 1.0, sums[k])
             if experiment_tracker is not None and batch_idx % log_interval == 0:
                 bm = {k: float(out[s_]) for k, s_ in zip(keys, ["g_total", "d_loss", "real_loss", "fake_loss"])}
-                if boundary_cfg > 0:
-                    bm["boundary_loss"] = float(criterion.boundary_loss(out["gen"], real, masks))
+                if boundary_cfg > 0:                     # train.py:235-257: boundary quality + the boundary loss term
+                    bm.update(calculate_boundary_quality(out["gen"], real, masks))
+                    bl = float(criterion.boundary_loss(out["gen"], real, masks))
+                    if bl > 0:
+                        bm["boundary_loss"] = bl
                 experiment_tracker.log_training_batch(pred=out["gen"], target=real, model=generator, optimizer=optimizer_G,
                                                       batch_metrics=bm, step=epoch * len(train_loader) + batch_idx)
         nb = max(len(train_loader), 1)

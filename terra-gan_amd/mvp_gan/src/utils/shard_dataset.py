@@ -1,0 +1,118 @@
+"""Pre-decoded uint8 tile shards -- the accelerated form of the input pipeline.
+
+The reference decodes two PNGs per sample with PIL inside the training loop (`InpaintingDataset`, dataset.py:8-43,
+`num_workers=0`, train.py:67-81): at MI355X step rates that loader, not the GPU, sets the pace.  A shard holds the SAME
+data one step further along: every tile and mask already decoded ('L') and resized with PIL's bilinear filter to the
+training size -- exactly `Resize((512,512))` of train.py:68 -- as uint8 arrays `images[N][H][W]`, `masks[N][H][W]` in one
+.npz-style directory of .npy files (memory-mapped, never loaded whole).  What the reference does AFTER the resize,
+`/255` (ToTensor) and `mask > 0` (dataset.py:35-37), happens on the device in tg_u8_to_tiles, so a batch crosses PCIe as
+1 byte per pixel and no host arithmetic is left in the loop.  Results are bit-identical to the PNG path
+(tests/test_hip_next_rows.py::test_shard_loader_bit_exact).
+
+    python -m mvp_gan.src.utils.shard_dataset build <img_dir> <mask_dir> <out_dir> [--size 512]
+"""
+import json
+import os
+
+import numpy as np
+import torch
+from PIL import Image
+
+META = "shard.json"
+
+
+def build_shard(img_dir, mask_dir, out_dir, size=(512, 512)):
+    """Decode + resize every (image, mask) pair once.  File pairing is the reference's: both directories sorted by name
+    (dataset.py:13-14)."""
+    imgs = sorted(f for f in os.listdir(img_dir) if os.path.isfile(os.path.join(img_dir, f)))
+    msks = sorted(f for f in os.listdir(mask_dir) if os.path.isfile(os.path.join(mask_dir, f)))
+    assert len(imgs) == len(msks), "Number of images and masks do not match."
+    os.makedirs(out_dir, exist_ok=True)
+    n, (h, w) = len(imgs), size
+    im = np.lib.format.open_memmap(os.path.join(out_dir, "images.npy"), mode="w+", dtype=np.uint8, shape=(n, h, w))
+    mk = np.lib.format.open_memmap(os.path.join(out_dir, "masks.npy"), mode="w+", dtype=np.uint8, shape=(n, h, w))
+    for i, (a, b) in enumerate(zip(imgs, msks)):
+        im[i] = np.asarray(Image.open(os.path.join(img_dir, a)).convert("L").resize((w, h), Image.BILINEAR), dtype=np.uint8)
+        mk[i] = np.asarray(Image.open(os.path.join(mask_dir, b)).convert("L").resize((w, h), Image.BILINEAR), dtype=np.uint8)
+    im.flush()
+    mk.flush()
+    with open(os.path.join(out_dir, META), "w") as f:
+        json.dump({"n": n, "height": h, "width": w, "images": imgs, "masks": msks, "format": "uint8 'L', PIL bilinear resize"}, f)
+    return out_dir
+
+
+def is_shard(path):
+    return os.path.isdir(path) and os.path.exists(os.path.join(path, META))
+
+
+class ShardLoader:
+    """Iterates {'image', 'mask'} batches as [B,1,H,W] fp32 DEVICE tensors straight from a shard directory.
+
+    Same batch composition rules as the reference's DataLoader(shuffle=..., drop_last=False); `sampler` (e.g.
+    tg_hip.dist.ShardSampler for data-parallel runs) overrides the index order.  Host work per batch: one fancy-index
+    gather of uint8 rows into a pinned buffer and one async H2D copy."""
+
+    def __init__(self, shard_dir, batch_size, shuffle=False, device=None, sampler=None, seed=None):
+        meta = json.load(open(os.path.join(shard_dir, META)))
+        self.n, self.h, self.w = meta["n"], meta["height"], meta["width"]
+        self.images = np.load(os.path.join(shard_dir, "images.npy"), mmap_mode="r")
+        self.masks = np.load(os.path.join(shard_dir, "masks.npy"), mmap_mode="r")
+        self.batch_size, self.shuffle, self.sampler = batch_size, shuffle, sampler
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.gen = torch.Generator()
+        if seed is not None:
+            self.gen.manual_seed(seed)
+        self._pin = [torch.empty((2, batch_size, self.h, self.w), dtype=torch.uint8).pin_memory() for _ in range(2)] \
+            if torch.cuda.is_available() else None
+        self._ev = [None, None]
+
+    def __len__(self):
+        n = len(self.sampler) if self.sampler is not None else self.n
+        return (n + self.batch_size - 1) // self.batch_size
+
+    def order(self):
+        if self.sampler is not None:
+            return list(self.sampler)
+        if self.shuffle:
+            return torch.randperm(self.n, generator=self.gen).tolist()
+        return list(range(self.n))
+
+    def host_batch(self, idx):
+        """uint8 [2][b][H][W] (images, masks) of the samples `idx`."""
+        srt = np.argsort(idx)                       # memmap reads in file order, then back to batch order
+        inv = np.empty_like(srt)
+        inv[srt] = np.arange(len(idx))
+        ii = np.asarray(idx)[srt]
+        return np.stack([self.images[ii][inv], self.masks[ii][inv]])
+
+    def __iter__(self):
+        from tg_hip import ops as O
+        order = self.order()
+        for bi, s in enumerate(range(0, len(order), self.batch_size)):
+            idx = order[s:s + self.batch_size]
+            slot = bi & 1
+            if self._ev[slot] is not None:
+                self._ev[slot].synchronize()        # the copy that last used this pinned buffer has finished
+            stage = self._pin[slot][:, :len(idx)]
+            stage.copy_(torch.from_numpy(self.host_batch(idx)))
+            dev = stage.to(self.device, non_blocking=True)
+            self._ev[slot] = torch.cuda.Event()
+            self._ev[slot].record()
+            img, msk = O.u8_to_tiles(dev[0].contiguous(), dev[1].contiguous())
+            yield {"image": img.unsqueeze(1), "mask": msk.unsqueeze(1)}
+
+
+def _main(argv):
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m mvp_gan.src.utils.shard_dataset")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    b = sub.add_parser("build")
+    b.add_argument("img_dir"), b.add_argument("mask_dir"), b.add_argument("out_dir")
+    b.add_argument("--size", type=int, default=512)
+    a = ap.parse_args(argv)
+    print(build_shard(a.img_dir, a.mask_dir, a.out_dir, (a.size, a.size)))
+
+
+if __name__ == "__main__":
+    import sys
+    _main(sys.argv[1:])

@@ -88,3 +88,58 @@ class GradSync:
 
 def _dense(p):
     return p.is_contiguous() or (p.dim() == 4 and p.permute(0, 2, 3, 1).is_contiguous())
+
+
+# --------------------------------------------------------------------------------------------------
+# what a data-parallel train() needs besides the gradient exchange
+# --------------------------------------------------------------------------------------------------
+def rank_world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def broadcast_state(modules=(), optimizers=(), src=0, group=None):
+    """Make every rank start from rank `src`'s parameters, buffers and optimiser state ("identical weights").
+    Without this, replicas built from different seeds (or resumed from different files) would silently average gradients
+    taken at different weights.  Tensors are broadcast in place, so parameter storage -- and with it the gradient
+    buffers and Adam tables -- stays where it is."""
+    rank, world = rank_world(group)
+    if world == 1:
+        return
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            dist.broadcast(t.data, src=src, group=group)
+    for opt in optimizers:
+        # state may be empty on some ranks only if it is empty on all (a fresh optimiser): exchange the structure first
+        meta = [opt.state_dict()] if rank == src else [None]
+        dist.broadcast_object_list(meta, src=src, group=group)
+        if rank != src and meta[0]["state"]:
+            opt.load_state_dict(meta[0])       # Optimizer.load_state_dict moves the state to each parameter's device
+
+
+class ShardSampler(torch.utils.data.Sampler):
+    """Per-rank index split of a dataset (DistributedSampler semantics): one shared permutation per epoch (seed + epoch),
+    padded by wrap-around to a multiple of world so every rank draws the same number of batches -- the gradient all-reduces
+    of the ranks pair up one to one."""
+
+    def __init__(self, n, rank, world, shuffle=True, seed=0):
+        self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch = n, rank, world, shuffle, seed, 0
+        self.per_rank = (n + world - 1) // world
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.per_rank
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            idx = torch.randperm(self.n, generator=g).tolist()
+        else:
+            idx = list(range(self.n))
+        total = self.per_rank * self.world
+        while len(idx) < total:
+            idx += idx[:total - len(idx)]
+        return iter(idx[self.rank:total:self.world])

@@ -78,6 +78,7 @@ def join_side():
 def _pconv_fwd(P, name, k, s, p, x, in_mask, ratio, training, premasked=False):
     """premasked: x already holds input*mask (the decoder concat is written that way), so the conv and its
     wgrad skip the mask prologue; dgrad still applies the mask."""
+    O.tag(f"{name}.fwd")
     y = O.conv_fwd(x, P[f"{name}.input_conv.weight"], P[f"{name}.input_conv.bias"].detach(), k, s, p,
                    in_mask=None if premasked else in_mask, ratio=ratio)
     if training:
@@ -99,9 +100,11 @@ def _pconv_bwd(P, c, da, grads, dx_out=None, want_dx=True, gbuf=None):
                                           ratio=c.ratio, outs=outs)
     # dgrad first: the weight gradient is enqueued behind it on the side stream, so it starts when the dgrad has
     # finished and runs underneath the NEXT layer's BatchNorm-backward reductions (small grids) and its dgrad
+    O.tag(f"{name}.dgrad")
     dx = O.conv_dgrad(dyr, P[f"{name}.input_conv.weight"], tuple(c.x.shape), c.k, c.s, c.p, in_mask=c.in_mask, out=dx_out) \
         if want_dx else None
     wmask = None if getattr(c, "premasked", False) else c.in_mask
+    O.tag(f"{name}.wgrad")
     dw, _ = _wgrad(gbuf, (c.x, dyr, wmask), lambda: O.conv_wgrad(
         c.x, dyr, P[f"{name}.input_conv.weight"], c.k, c.s, c.p, in_mask=wmask, want_bias=False,
         dw_out=gbuf[f"{name}.input_conv.weight"] if gbuf is not None else None))
@@ -150,6 +153,7 @@ def generator_forward(P, x, mask, training=True, checkpoint=False):
         if checkpoint:
             c.x = None                                               # concat tensor: rebuilt in backward
         dec_ctx.append(c)
+    O.tag("final.fwd")
     logits = O.conv_fwd(d, P["final.weight"], P["final.bias"].detach(), 3, 1, 1)      # generator.py:29,56
     out = O.sigmoid_composite_fwd(logits.reshape(B, H, W), x, mask)                     # generator.py:57-62
     if checkpoint:
@@ -174,7 +178,9 @@ def generator_backward(P, ctx, dout, want_dx=False, gbuf=None):
     dz, dx_comp = O.sigmoid_composite_bwd(dout, ctx.logits.reshape(B, H, W), ctx.mask, want_dx)
     dz = dz.reshape(B, H, W, 1)
     d0 = _act_of(P, ctx.dec[6]) if ckpt else ctx.d0
+    O.tag("final.dgrad")
     da = O.conv_dgrad(dz, P["final.weight"], tuple(d0.shape), 3, 1, 1)
+    O.tag("final.wgrad")
     grads["final.weight"], grads["final.bias"] = _wgrad(gbuf, (d0, dz), lambda: O.conv_wgrad(
         d0, dz, P["final.weight"], 3, 1, 1, dw_out=gbuf["final.weight"] if gbuf is not None else None,
         db_out=gbuf["final.bias"] if gbuf is not None else None))
@@ -229,6 +235,7 @@ def discriminator_forward(P, img, training=True, groups=1, update_running=True):
     layers = []
     for (ci, bi, _cin, _cout, k, s, p, leaky) in D_LAYERS:
         w, b = P[f"model.{ci}.weight"], P[f"model.{ci}.bias"].detach()
+        O.tag(f"d{ci}.fwd")
         if bi is None:
             act = O.ACT_LEAKY if leaky else O.ACT_NONE
             a = O.conv_fwd(h, w, b, k, s, p, act=act, slope=0.2)
@@ -302,6 +309,7 @@ def discriminator_backward(P, ctx, dlogits, want_wgrad=True, want_dimg=False, gb
             if want_wgrad:
                 grads[f"model.{c.bi}.weight"], grads[f"model.{c.bi}.bias"] = dgamma, dbeta
         gated = False
+        O.tag(f"d{c.ci}.dgrad")
         if li > 0 or want_dimg:
             below = ctx.layers[li - 1] if li > 0 else None
             if below is not None and below.bi is None and below.act != O.ACT_NONE:
@@ -311,6 +319,7 @@ def discriminator_backward(P, ctx, dlogits, want_wgrad=True, want_dimg=False, gb
                 da = O.conv_dgrad(dy, w, tuple(c.x.shape), c.k, c.s, c.p)
         else:
             da = None
+        O.tag(f"d{c.ci}.wgrad")
         if want_wgrad:       # behind the dgrad, see _pconv_bwd
             dw, db2 = _wgrad(gbuf, (c.x, dy), lambda c=c, dy=dy, w=w, db=db: O.conv_wgrad(
                 c.x, dy, w, c.k, c.s, c.p, want_bias=db is None,
@@ -349,6 +358,7 @@ def vgg_forward(V, img, keep=True):
                 steps.append(NS(kind="M", x=h))
         else:
             w = V["0.folded"] if item == 0 else V[f"{item}.weight"]
+            O.tag(f"vgg{item}.fwd")
             o = O.conv_fwd(h, w, V[f"{item}.bias"], 3, 1, 1, act=O.ACT_RELU)
             if keep:
                 steps.append(NS(kind="C", w=w, x_shape=tuple(h.shape), a=o))
@@ -372,6 +382,7 @@ def vgg_backward(ctx, dfeat, nb=None):
             dy = da if gated else O.act_bwd(da, a, O.ACT_RELU)
             shp = st.x_shape if nb is None else (nb,) + tuple(st.x_shape[1:])
             below = steps[i - 1] if i > 0 else None
+            O.tag(f"vgg{VGG_TRUNK[i]}.dgrad")
             if below is not None and below.kind == "C":      # input of this conv = ReLU output of the conv below
                 ga = below.a if nb is None else below.a[:nb]
                 da = O.conv_dgrad(dy, st.w, shp, 3, 1, 1, gate=ga, gate_act=O.ACT_RELU)

@@ -59,9 +59,13 @@ SIGNATURES = {
     "tg_lincomb": (I, [P, F, P, F, P, I64, P]),
     "tg_mul": (I, [P, P, P, I64, P]),
     "tg_bn_running_update": (I, [P, P, I64, I, F, F, P, P, P, P]),
+    "tg_quality_metrics_ws_bytes": (SZ, [I64, I, I]),
+    "tg_quality_metrics": (I, [P, P, P, I64, I, I, P, P, SZ, P]),
+    "tg_u8_to_tiles": (I, [P, P, I64, P, P, P]),
     "tg_prof_enable": (I, [I]),
     "tg_prof_summary": (I, [I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tg_prof_dump": (I, [C.c_char_p]),
+    "tg_prof_tag": (I, [C.c_char_p]),
     "tg_nchw_to_nhwc": (I, [P, I, I, I, I, P, P]),
     "tg_nhwc_to_nchw": (I, [P, I, I, I, I, P, P]),
 }

@@ -22,6 +22,12 @@ def set_precision(name):
 def get_precision():
     return "bf16" if _precision == PREC_BF16 else "f32"
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+PROF_TAGS = False        # bench.py's instrumented pass: label conv launches with their layer (tg_prof_tag)
+
+
+def tag(name):
+    if PROF_TAGS:
+        _lib().tg_prof_tag(name.encode())
 
 _ws = {}
 
@@ -317,6 +323,36 @@ def bce_logits(z, target, coef=1.0, gscale=None, want_grad=True):
     L.check(lib.tg_bce_logits(_p(z), z.numel(), target, coef, _p(gscale), _p(out), _p(dz), _p(ws), ws.numel() * 4, _stream()),
             "tg_bce_logits")
     return out, dz
+
+
+QUALITY_KEYS = ("mse", "psnr", "ssim", "l1_distance", "l2_distance", "boundary_mse", "boundary_psnr",
+                "boundary_gradient_diff", "boundary_sum")
+
+
+def quality_metrics(pred, target, mask):
+    """-> 9-element device tensor, QUALITY_KEYS order (tg_quality_metrics); pred/target/mask [B,1,H,W] or [B,H,W]."""
+    _chk(pred, "pred"); _chk(target, "target"); _chk(mask, "mask")
+    H, W = pred.shape[-2], pred.shape[-1]
+    imgs = pred.numel() // (H * W)
+    assert target.shape == pred.shape and mask.numel() == pred.numel(), (pred.shape, target.shape, mask.shape)
+    out = empty(9, like=pred)
+    lib = _lib()
+    ws = workspace(lib.tg_quality_metrics_ws_bytes(imgs, H, W))
+    L.check(lib.tg_quality_metrics(_p(pred), _p(target), _p(mask), imgs, H, W, _p(out), _p(ws), ws.numel() * 4, _stream()),
+            "tg_quality_metrics")
+    return out
+
+
+def u8_to_tiles(img_u8=None, mask_u8=None):
+    """uint8 device tensors -> (image/255, mask>0) fp32 device tensors of the same shape (tg_u8_to_tiles)."""
+    ref = img_u8 if img_u8 is not None else mask_u8
+    for t in (img_u8, mask_u8):
+        if t is not None and (not t.is_cuda or t.dtype != torch.uint8 or not t.is_contiguous()):
+            raise L.TgError("u8_to_tiles: expected contiguous uint8 HIP tensors")
+    img = torch.empty(ref.shape, dtype=torch.float32, device=ref.device) if img_u8 is not None else None
+    msk = torch.empty(ref.shape, dtype=torch.float32, device=ref.device) if mask_u8 is not None else None
+    L.check(_lib().tg_u8_to_tiles(_p(img_u8), _p(mask_u8), ref.numel(), _p(img), _p(msk), _stream()), "tg_u8_to_tiles")
+    return img, msk
 
 
 def _dense_layouts(t):

@@ -388,17 +388,87 @@ def gen_init(ref_gen, ref_disc, ref_losses):
     return out
 
 
+def gen_steps_unc():
+    """fp32-vs-fp64 deviation of the step fixtures' quantities, from the oracle (the reference itself cannot run in
+    fp64: pconv.py:35,40 hard-code .float(); the oracle is pinned to the reference in fp32 by steps.npz).  The GPU parity
+    tests bound their error by the stated fp32 tolerance + k x this deviation: a result inside the
+    reference arithmetic's own fp32 uncertainty cannot be told from the reference."""
+    from oracle import terragan_oracle as Orc
+    out = {}
+
+    def state(dtype):
+        st = Orc.TrainState(0)
+        for d in (st.gp, st.dp, st.vp):
+            for k in d:
+                if d[k].dtype.is_floating_point:
+                    d[k] = d[k].to(dtype)
+        st.opt_g = Orc.Adam(st.gp, Orc.trainable(st.gp), 2e-4)
+        st.opt_d = Orc.Adam(st.dp, Orc.trainable(st.dp), 2e-4)
+        return st
+
+    def dev4(a, c):
+        a, c = a.double().flatten(), c.double().flatten()
+        d = a - c
+        return np.array([float(d.abs().max()), float(d.abs().sum()), float(d.norm()), float(a.abs().max())])
+
+    def run(dtype, b, size, nsteps, seed0):
+        st = state(dtype)
+        res = []
+        for s in range(nsteps):
+            real, mask = synth_batch(b, size, seed0 + s)
+            gen, sc, gg, dg = Orc.train_step(st, real.to(dtype), mask.to(dtype))
+            w = {f"G.{k}": st.gp[k].double().clone() for k in Orc.trainable(st.gp)}
+            w.update({f"D.{k}": st.dp[k].double().clone() for k in Orc.trainable(st.dp)})
+            bufs = {k: v.double().clone() for d in (st.gp, st.dp) for k, v in d.items() if "running" in k}
+            res.append((gen.double(), {k: float(v) for k, v in sc.items()}, gg, dg, w, bufs))
+        return res
+
+    for tag, b, size, nsteps, seed0 in [("c1_256", 1, 256, 3, 1), ("b4_128", 4, 128, 3, 40)]:
+        r32 = run(torch.float32, b, size, nsteps, seed0)
+        r64 = run(torch.float64, b, size, nsteps, seed0)
+        for s in range(nsteps):
+            for k in r32[s][1]:
+                out[f"{tag}/s{s}/{k}"] = np.float64(abs(r32[s][1][k] - r64[s][1][k]))
+            out[f"{tag}/s{s}/gen"] = np.float64((r32[s][0] - r64[s][0]).abs().max())
+            out[f"{tag}/s{s}/gen_mean"] = np.float64((r32[s][0] - r64[s][0]).abs().mean())
+            if s in (0, nsteps - 1):
+                for k in r32[s][4]:
+                    a, c = r32[s][4][k], r64[s][4][k]
+                    out[f"{tag}/s{s}/w/{k}"] = np.array([abs(float(a.sum() - c.sum())), abs(float(a.abs().sum() - c.abs().sum()))])
+                for k in r32[s][5]:
+                    out[f"{tag}/s{s}/buf/{k}"] = np.float64((r32[s][5][k] - r64[s][5][k]).abs().max())
+        for kind, idx in (("ggrad", 2), ("dgrad", 3)):
+            for k in r32[0][idx]:
+                out[f"{tag}/s0/{kind}/{k}"] = dev4(r32[0][idx][k], r64[0][idx][k])     # [max|d|, sum|d|, ||d||, max|g|]
+    # data-parallel emulations (SURVEY 8e): N micro-batches, mean gradients, one Adam step
+    for tag, n, b, size in [("dp2_128", 2, 4, 128), ("dp8_128", 8, 4, 128)]:
+        batches = [synth_batch(b, size, 1000 + r) for r in range(n)]
+        rr = {}
+        for dtype in (torch.float32, torch.float64):
+            st = state(dtype)
+            _gens, scal = Orc.dp_train_step(st, [x.to(dtype) for x, _ in batches], [m.to(dtype) for _, m in batches])
+            rr[dtype] = (scal, st.last_gg, st.last_dg, st)
+        (s32, gg32, dg32, st32), (s64, gg64, dg64, st64) = rr[torch.float32], rr[torch.float64]
+        for r in range(n):
+            for k in ("g_total", "d_loss"):
+                out[f"{tag}/r{r}/{k}"] = np.float64(abs(float(s32[r][k]) - float(s64[r][k])))
+        for k in gg32:
+            out[f"{tag}/ggrad/{k}"] = dev4(gg32[k], gg64[k])
+        for k in dg32:
+            out[f"{tag}/dgrad/{k}"] = dev4(dg32[k], dg64[k])
+        for pre, d32, d64 in (("G", st32.gp, st64.gp), ("D", st32.dp, st64.dp)):
+            for k in Orc.trainable(d32):
+                a, c = d32[k].double(), d64[k].double()
+                out[f"{tag}/w/{pre}.{k}"] = np.array([abs(float(a.sum() - c.sum())), abs(float(a.abs().sum() - c.abs().sum()))])
+    return out
+
+
 def main():
-    ref_pconv, ref_gen, ref_disc, ref_losses = _load_reference()
-    jobs = {
-        "pconv_layers": lambda: gen_pconv(ref_pconv),
-        "models": lambda: gen_models(ref_gen, ref_disc),
-        "losses": lambda: gen_losses(ref_losses),
-        "init": lambda: gen_init(ref_gen, ref_disc, ref_losses),
-        "steps": lambda: gen_steps(ref_gen, ref_disc, ref_losses),
-        "steps_dp8": lambda: gen_dp(ref_gen, ref_disc, ref_losses, [("dp8_128", 8, 4, 128)]),
-    }
     only = sys.argv[1:]
+    jobs = {"steps_unc": gen_steps_unc}           # oracle only: does not need the reference
+    if only != ["steps_unc"]:
+        ref_pconv, ref_gen, ref_disc, ref_losses = _load_reference()
+        jobs.update(_reference_jobs(ref_pconv, ref_gen, ref_disc, ref_losses))
     for name, fn in jobs.items():
         if only and name not in only:
             continue
@@ -406,6 +476,75 @@ def main():
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **data)
         print(f"{name}: {len(data)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def gen_metrics():
+    """Logged quality metrics from the reference's own evaluation/metrics.py (calculate_boundary_quality :79-133 and
+    MaskEvaluator._calculate_psnr/_calculate_ssim :47-76, the same arithmetic as utils/experiment_tracking.py:196-231).
+    The module imports cv2 at the top for its OpenCV contour helper only; cv2 is absent here and is stubbed with an
+    empty module (none of the functions used below touch it)."""
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    spec = importlib.util.spec_from_file_location("refpkg_metrics", os.path.join(REF, "mvp_gan/src/evaluation/metrics.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ev = mod.MaskEvaluator({})
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    cases = [("q48x40", 2, 48, 40, "blocks"), ("q64", 1, 64, 64, "holes30"), ("q33x70", 3, 33, 70, "border"),
+             ("qones", 2, 32, 32, "ones"), ("qsame", 1, 40, 40, "blocks")]
+    for tag, b, h, w, kind in cases:
+        tgt = torch.rand(b, 1, h, w, generator=g)
+        pred = tgt.clone() if tag == "qsame" else (tgt + 0.1 * torch.randn(b, 1, h, w, generator=g)).clamp(0, 1)
+        m = mask_case(kind, b, h, w, g)
+        out[f"{tag}/pred"], out[f"{tag}/target"], out[f"{tag}/mask"] = pred.numpy(), tgt.numpy(), m.numpy().astype(np.uint8)
+        bq = mod.calculate_boundary_quality(pred, tgt, m)
+        for k, v in bq.items():
+            out[f"{tag}/{k}"] = np.float64(v)
+        out[f"{tag}/psnr"] = np.float64(ev._calculate_psnr(pred, tgt))
+        out[f"{tag}/ssim"] = np.float64(ev._calculate_ssim(pred, tgt))
+        # utils/experiment_tracking.py:187-188 (that module needs mlflow/psutil/git to import; these two lines are plain torch)
+        out[f"{tag}/l1_distance"] = np.float64(torch.nn.functional.l1_loss(pred, tgt).item())
+        out[f"{tag}/l2_distance"] = np.float64(torch.nn.functional.mse_loss(pred, tgt, reduction="mean").sqrt().item())
+    return out
+
+
+def gen_validation(ref_gen, ref_disc, ref_losses):
+    """Validation body of the reference loop (train.py:278-301) after one train step: G.eval(), D left in train mode."""
+    out = {}
+    bce = nn.BCEWithLogitsLoss()
+    for tag, b, size in [("v2_128", 2, 128), ("v1_256", 1, 256)]:
+        G, D, crit, oG, oD = _build(ref_gen, ref_disc, ref_losses)
+        G.train(), D.train()
+        real, mask = synth_batch(b, size, 70)
+        _ref_step(G, D, crit, bce, oG, oD, real, mask)          # non-trivial running statistics and weights
+        G.eval()
+        vreal, vmask = synth_batch(b, size, 71)
+        with torch.no_grad():
+            gen = G(vreal * vmask, vmask)
+            g_total = crit(gen, vreal, vmask)
+            rv, fv = D(vreal), D(gen)
+            d = 0.5 * (bce(rv, torch.ones_like(rv)).item() + bce(fv, torch.zeros_like(fv)).item())
+        out[f"{tag}/cfg"] = np.array([b, size], dtype=np.int64)
+        out[f"{tag}/val_g_loss"], out[f"{tag}/val_d_loss"] = np.float64(float(g_total)), np.float64(d)
+        put(out, f"{tag}/gen", gen, full_limit=70000)
+        for n, buf in D.named_buffers():
+            if "running" in n:
+                put(out, f"{tag}/dbuf/{n}", buf, full_limit=1024)
+        out[f"{tag}/d_nbt"] = np.int64(int(D.model[3].num_batches_tracked))
+    return out
+
+
+def _reference_jobs(ref_pconv, ref_gen, ref_disc, ref_losses):
+    return {
+        "metrics": gen_metrics,
+        "validation": lambda: gen_validation(ref_gen, ref_disc, ref_losses),
+        "pconv_layers": lambda: gen_pconv(ref_pconv),
+        "models": lambda: gen_models(ref_gen, ref_disc),
+        "losses": lambda: gen_losses(ref_losses),
+        "init": lambda: gen_init(ref_gen, ref_disc, ref_losses),
+        "steps": lambda: gen_steps(ref_gen, ref_disc, ref_losses),
+        "steps_dp8": lambda: gen_dp(ref_gen, ref_disc, ref_losses, [("dp8_128", 8, 4, 128)]),
+    }
 
 
 if __name__ == "__main__":

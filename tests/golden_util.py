@@ -45,3 +45,81 @@ def _cmp(key, t, ref, atol, rtol, scale_by_max):
         bad = err > (atol + rtol * ref.abs())
         assert not bool(bad.any()), (f"{key}: {int(bad.sum())}/{t.numel()} off, max err "
                                      f"{float(err.max()):.3e} (ref max {float(ref.abs().max()):.3e})")
+
+
+# --------------------------------------------------------------------------------------------------
+# stated tolerance + the reference arithmetic's own fp32 uncertainty (tests/golden/steps_unc.npz)
+# --------------------------------------------------------------------------------------------------
+K_UNC = 5.0          # how many fp32-vs-fp64 deviations of the oracle a result may sit away from the reference
+K_DRIFT = 20.0       # same, for quantities AFTER an Adam update (steps >= 1): two fp32 trajectories separate chaotically
+_ratios = {}
+_failures = []
+
+
+def begin():
+    _ratios.clear()
+    _failures.clear()
+
+
+def expect(ok, msg):
+    """Deferred assertion: a parity test reports ALL its violations (and still writes its ratio table) before failing."""
+    if not ok:
+        _failures.append(msg)
+
+
+def finish(name):
+    dump_ratios(name)
+    assert not _failures, f"{len(_failures)} parity violations:\n  " + "\n  ".join(str(f) for f in _failures[:40])
+
+
+def record(group, key, ratio, err=None, bound=None):
+    """Keep the worst err/bound ratio per group; tests dump them with dump_ratios() (evidence for the parity report)."""
+    g = _ratios.setdefault(group, {"worst_ratio": 0.0, "worst_key": None, "n": 0})
+    g["n"] += 1
+    if ratio >= g["worst_ratio"]:
+        g.update(worst_ratio=float(ratio), worst_key=key, err=None if err is None else float(err),
+                 bound=None if bound is None else float(bound))
+
+
+def dump_ratios(name):
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out", "parity")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, name + ".json"), "w") as f:
+            json.dump(_ratios, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    print("\nparity ratios (err / bound, worst per group):")
+    for g, v in sorted(_ratios.items()):
+        print(f"  {g:32s} {v['worst_ratio']:.3f}  ({v['worst_key']}, err {v.get('err')}, bound {v.get('bound')}, n={v['n']})")
+
+
+def check_unc(gold, unc, key, t, group, rel=1e-3, atol=1e-10, k=None):
+    """Gradient rule of SURVEY 8c, max|d| <= rel*max|g|, plus k x the oracle's fp32-vs-fp64 deviation of the SAME tensor
+    (unc[key] = [max|d|, sum|d|, ||d||_2, max|g|]).  Returns the worst err/bound ratio (asserted <= 1)."""
+    k = K_UNC if k is None else k
+    t = t.detach().double().flatten().cpu()
+    umax, usum, ul2, gmax = [float(v) for v in unc[key]]
+    bound = rel * gmax + k * umax + atol
+    checks = []
+    if key + "/full" in gold:
+        ref = torch.from_numpy(gold[key + "/full"]).double()
+        assert ref.numel() == t.numel(), f"{key}: numel {t.numel()} vs {ref.numel()}"
+        checks.append(("max", float((t - ref).abs().max()), bound))
+    else:
+        stride = int(gold[key + "/stride"])
+        ref = torch.from_numpy(gold[key + "/sample"]).double()
+        n = t.numel()
+        checks.append(("sample max", float((t[::stride][:512] - ref).abs().max()), bound))
+        checks.append(("sum", abs(float(t.sum()) - float(gold[key + "/sum"])),
+                       rel * float(gold[key + "/abssum"]) + k * usum + atol * n))
+        l2 = float(gold[key + "/l2"])
+        checks.append(("l2", abs(float(t.norm()) - l2), rel * l2 + k * ul2 + atol * n ** 0.5))
+    worst = 0.0
+    for what, err, bnd in checks:
+        record(group, f"{key} [{what}]", err / bnd, err, bnd)
+        expect(err <= bnd, f"{key} [{what}]: err {err:.3e} > bound {bnd:.3e} (oracle fp32-vs-fp64 max dev {umax:.3e}, max|g| {gmax:.3e})")
+        worst = max(worst, err / bnd)
+    return worst

@@ -28,3 +28,28 @@ def test_dataset_resize_and_binarise(tmp_path):
     assert np.array_equal(img[0].numpy(), ref)
     mref = np.asarray(Image.open(tmp_path / "msk" / "t1_mask_resized.png").convert("L").resize((64, 64), Image.BILINEAR))
     assert np.array_equal(mask[0].numpy(), (mref > 0).astype(np.float32))      # binarised AFTER the resize (dataset.py:35-37)
+
+
+def test_shard_build_holds_the_resized_uint8_tiles(tmp_path):
+    """The uint8 shard (utils/shard_dataset.py) stores exactly what the PNG path has after `Resize` and before `/255` /
+    `> 0`; applying those two steps on the host to a shard batch reproduces InpaintingDataset bit for bit (the device-side
+    tg_u8_to_tiles does the same arithmetic: tests/test_hip_next_rows.py::test_shard_loader_bit_exact)."""
+    from mvp_gan.src.utils.shard_dataset import ShardLoader, build_shard, is_shard
+    rng = np.random.default_rng(5)
+    (tmp_path / "img").mkdir()
+    (tmp_path / "msk").mkdir()
+    for i in range(5):
+        Image.fromarray(rng.integers(0, 256, (60, 70), dtype=np.uint8), mode="L").save(tmp_path / "img" / f"t{i}.png")
+        Image.fromarray(rng.integers(0, 2, (60, 70), dtype=np.uint8) * rng.integers(1, 256, (60, 70), dtype=np.uint8),
+                        mode="L").save(tmp_path / "msk" / f"t{i}.png")
+    shard = build_shard(tmp_path / "img", tmp_path / "msk", tmp_path / "shard", (48, 40))
+    assert is_shard(str(shard))
+    ds = InpaintingDataset(str(tmp_path / "img"), str(tmp_path / "msk"), transform=resize_to_tensor((48, 40)))
+    ld = ShardLoader.__new__(ShardLoader)              # host side only: no GPU in this test
+    ld.images = np.load(tmp_path / "shard" / "images.npy", mmap_mode="r")
+    ld.masks = np.load(tmp_path / "shard" / "masks.npy", mmap_mode="r")
+    hb = ld.host_batch([3, 0, 4])
+    assert hb.shape == (2, 3, 48, 40) and hb.dtype == np.uint8
+    for j, i in enumerate([3, 0, 4]):
+        assert np.array_equal(hb[0, j].astype(np.float32) / 255.0, ds[i]["image"][0].numpy())
+        assert np.array_equal((hb[1, j] > 0).astype(np.float32), ds[i]["mask"][0].numpy())

@@ -77,3 +77,67 @@ def test_gradsync_two_ranks_gloo():
         for a, b, w in zip(out, out2, want):
             a, b = torch.from_numpy(a), torch.from_numpy(b)
             assert torch.allclose(a, w, atol=1e-6) and torch.allclose(b, w, atol=1e-6)
+
+
+def test_shard_sampler_partitions_every_epoch():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "terra-gan_amd"))
+    from tg_hip.dist import ShardSampler
+    for n, world in [(10, 2), (7, 4), (16, 8), (3, 8)]:
+        for epoch in range(3):
+            parts = []
+            for r in range(world):
+                sm = ShardSampler(n, r, world, shuffle=True, seed=5)
+                sm.set_epoch(epoch)
+                parts.append(list(sm))
+            assert len({len(p) for p in parts}) == 1 and len(parts[0]) == (n + world - 1) // world   # equal batch counts
+            flat = [i for p in parts for i in p]
+            assert set(flat) == set(range(n)) or n < world and set(flat) <= set(range(n))     # every sample is drawn
+            if n >= world:
+                assert len(flat) - len(set(flat)) == len(parts[0]) * world - n              # only the wrap-around padding repeats
+        a, b = ShardSampler(n, 0, world, seed=5), ShardSampler(n, 0, world, seed=5)
+        b.set_epoch(1)
+        if n >= 2 * world:
+            assert list(a) != list(b)                                                        # reshuffled per epoch
+
+
+def _bcast_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "terra-gan_amd"))
+    from tg_hip.dist import broadcast_state
+    torch.manual_seed(rank)                           # different weights per rank
+    m = nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8))
+    m[0].weight.data = m[0].weight.data.contiguous(memory_format=torch.channels_last)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    if rank == 0:                                     # only rank 0 has optimiser state (e.g. resumed from a checkpoint)
+        for p in m.parameters():
+            p.grad = torch.ones_like(p)
+        opt.step()
+        m[1].running_mean.fill_(0.25)
+    ptr = m[0].weight.data_ptr()
+    broadcast_state([m], [opt])
+    assert m[0].weight.data_ptr() == ptr              # in place: gradient buffers / Adam tables stay valid
+    st = opt.state[m[0].weight]
+    q.put((rank, m[0].weight.detach().numpy().copy(), m[1].running_mean.numpy().copy(), float(st["step"]),
+           st["exp_avg"].numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_broadcast_state_two_ranks_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r[1:]) for r in (q.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for a, b in zip(res[0], res[1]):
+        assert (torch.as_tensor(a) == torch.as_tensor(b)).all()
+    assert res[1][2] == 1.0 and float(res[1][1][0]) == 0.25

@@ -67,3 +67,99 @@ def test_bf16_train_step_losses(dev):
         out[prec] = vals
     for (g32, d32), (g16, d16) in zip(out["f32"], out["bf16"]):
         assert abs(g16 - g32) <= 2e-2 * abs(g32) and abs(d16 - d32) <= 2e-2 * abs(d32), (out["f32"], out["bf16"])
+
+
+def _build(dev, boundary_weight=0.5):
+    from mvp_gan.src.models import Discriminator, PConvUNet
+    from mvp_gan.src.utils.losses import InpaintingLoss
+    torch.manual_seed(0)
+    G, D = PConvUNet(), Discriminator()
+    crit = InpaintingLoss(0.1, 0.1, boundary_weight=boundary_weight, device=torch.device("cpu"))
+    G, D, crit = G.to(dev), D.to(dev), crit.to(dev)
+    return G, D, crit, torch.optim.Adam(G.parameters(), lr=2e-4), torch.optim.Adam(D.parameters(), lr=2e-4)
+
+
+def test_bf16_train_steps_vs_reference_golden(dev):
+    """BASELINE config 3 arithmetic against the REFERENCE: the c1_256 fixture of tests/golden/steps.npz (three train steps
+    of the reference's own modules, fp32 CPU) with the HIP path in bf16-operand mode; SURVEY 8c's bf16 rule: per-step
+    losses within rtol 2e-2 (not element-wise).  The generator output is additionally held to a mean abs error bound."""
+    from mvp_gan.src.train import train_step
+    from oracle import terragan_oracle as Orc
+    from tests import golden_util as GU
+    from tg_hip import ops as O
+    gold = GU.load("steps")
+    tag = "c1_256"
+    b, size, nsteps, seed0 = [int(v) for v in gold[f"{tag}/cfg"]]
+    O.set_precision("bf16")
+    G, D, crit, oG, oD = _build(dev)
+    worst = 0.0
+    for s in range(nsteps):
+        real, mask = Orc.synth_batch(b, size, seed0 + s)
+        out = train_step(G, D, crit, oG, oD, real.to(dev), mask.to(dev))
+        for k in ["g_total", "g_loss", "g_adv", "d_loss", "real_loss", "fake_loss"]:
+            ref = float(gold[f"{tag}/s{s}/{k}"])
+            rel = abs(float(out[k]) - ref) / abs(ref)
+            worst = max(worst, rel)
+            assert rel <= 2e-2, (s, k, float(out[k]), ref)
+        ref = torch.from_numpy(gold[f"{tag}/s{s}/gen/full"]).double()
+        mae = (out["gen"].detach().double().flatten().cpu() - ref).abs().mean().item()
+        assert mae <= 2e-3, (s, mae)
+    print(f"\nbf16 vs reference golden c1_256: worst relative loss error {worst:.3e}")
+
+
+# BASELINE config 3 at its full size (512x512, batch 8, boundary weight 0.5): the CPU oracle would need minutes, so the
+# bf16 kernels are held to size-independent properties (SURVEY 8c): fwd / dgrad / wgrad describe one bilinear form
+# (each rounds ITS operands to bf16, so the three evaluations agree to ~2^-9 / sqrt(terms)), and a whole train step is
+# bitwise reproducible.
+LAYERS_512 = [("dec1", 8, 512, 512, 64, 64, 3, 1, 1, True), ("dec2", 8, 256, 256, 192, 64, 3, 1, 1, True),
+              ("enc2", 8, 256, 256, 64, 128, 5, 2, 2, True), ("d2", 8, 128, 128, 128, 256, 4, 2, 1, False),
+              ("vgg1_2", 8, 512, 512, 64, 64, 3, 1, 1, False)]
+
+
+@pytest.mark.parametrize("layer", LAYERS_512, ids=[l[0] for l in LAYERS_512])
+def test_config3_bf16_conv_adjoint_fullsize(dev, layer):
+    from tg_hip import ops as O
+    _name, B, H, W, Cin, Cout, k, s, p, masked = layer
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.05).contiguous(memory_format=torch.channels_last).to(dev)
+    m = (torch.rand(B, H, W, generator=g) > 0.25).float().to(dev) if masked else None
+    O.set_precision("bf16")
+    y = O.conv_fwd(x, w, None, k, s, p, in_mask=m)
+    dy = torch.randn(y.shape, generator=g).to(dev)
+    dx = O.conv_dgrad(dy, w, tuple(x.shape), k, s, p, in_mask=m)
+    dw, _db = O.conv_wgrad(x, dy, w, k, s, p, in_mask=m)
+    O.set_precision("f32")
+    y32 = O.conv_fwd(x, w, None, k, s, p, in_mask=m)
+    dot = lambda a, b_: float((a.double() * b_.double()).sum())
+    lhs = dot(y, dy)
+    scale = float(y.double().norm() * dy.double().norm())
+    assert abs(lhs - dot(x, dx)) <= 2e-3 * scale, ("dgrad adjoint", lhs, dot(x, dx), scale)
+    assert abs(lhs - dot(w, dw)) <= 2e-3 * scale, ("wgrad adjoint", lhs, dot(w, dw), scale)
+    rel = float((y - y32).double().norm() / y32.double().norm())
+    assert 1e-5 < rel < 1e-2, rel              # bf16 operands: really used, and no worse than 2^-7
+
+
+def test_config3_bf16_train_step_fullsize(dev):
+    """512x512, batch 8, bf16 operands, boundary weight 0.5: two identical runs of two steps are bitwise equal, losses are
+    finite and within rtol 2e-2 of the fp32 path at the same size."""
+    from mvp_gan.src.train import train_step
+    from oracle import terragan_oracle as Orc
+    from tg_hip import ops as O
+    real, mask = Orc.synth_batch(8, 512, 2001)
+    real, mask = real.to(dev), mask.to(dev)
+    runs = {}
+    for name, prec in (("bf16_a", "bf16"), ("bf16_b", "bf16"), ("f32", "f32")):
+        O.set_precision(prec)
+        G, D, crit, oG, oD = _build(dev, boundary_weight=0.5)
+        assert crit.boundary_weight == 0.5
+        losses = []
+        for _s in range(2):
+            out = train_step(G, D, crit, oG, oD, real, mask)
+            losses.append((float(out["g_total"]), float(out["d_loss"])))
+        runs[name] = (losses, [p_.detach().clone() for p_ in list(G.parameters()) + list(D.parameters())])
+    assert runs["bf16_a"][0] == runs["bf16_b"][0]
+    for a, b_ in zip(runs["bf16_a"][1], runs["bf16_b"][1]):
+        assert torch.equal(a, b_)
+    for (g16, d16), (g32, d32) in zip(runs["bf16_a"][0], runs["f32"][0]):
+        assert g16 == g16 and abs(g16 - g32) <= 2e-2 * abs(g32) and abs(d16 - d32) <= 2e-2 * abs(d32), (runs["bf16_a"][0], runs["f32"][0])

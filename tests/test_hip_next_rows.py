@@ -140,3 +140,197 @@ def test_train_end_to_end_tiny_dataset(dev, tmp_path):
     oG = torch.optim.Adam(G2.parameters(), lr=2e-4)
     oG.load_state_dict(ck["optimizer_G_state_dict"])            # the HIP Adam keeps torch's optimizer state format
     assert (tmp_path / "checkpoint_epoch_0.pth").exists()
+
+
+QUALITY_CASES = ["q48x40", "q64", "q33x70", "qones", "qsame"]
+
+
+@pytest.mark.parametrize("tag", QUALITY_CASES)
+def test_quality_metrics_golden(dev, tag):
+    """tg_quality_metrics (one pass, no host sync) against the reference's own evaluation/metrics.py outputs
+    (tests/golden/metrics.npz) through the mirrored API: calculate_boundary_quality + psnr / ssim / l1 / l2."""
+    from tests import golden_util as GU
+    from mvp_gan.src.evaluation import metrics as M
+    gold = GU.load("metrics")
+    pred, tgt = torch.from_numpy(gold[f"{tag}/pred"]).to(dev), torch.from_numpy(gold[f"{tag}/target"]).to(dev)
+    m = torch.from_numpy(gold[f"{tag}/mask"]).float().to(dev)
+    bq = M.calculate_boundary_quality(pred, tgt, m)
+    assert set(bq) == {"boundary_mse", "boundary_psnr", "boundary_gradient_diff"}
+    got = dict(bq)
+    got.update(M.performance_metrics(pred, tgt))
+    assert got["psnr"] == M.calculate_psnr(pred, tgt) and got["ssim"] == M.calculate_ssim(pred, tgt)
+    # fp32 sums in another order than ATen's: mse / l1 are fp64-accumulated here (closer to exact than the reference);
+    # SSIM's E[x^2] - mu^2 cancels ~3 digits, so its window sums carry ~1e-4 relative noise locally, ~1e-6 on the mean
+    tol = {"ssim": 2e-5, "boundary_psnr": 2e-5, "psnr": 2e-5}
+    for k, v in got.items():
+        ref = float(gold[f"{tag}/{k}"])
+        if ref == float("inf"):
+            assert v == float("inf"), (tag, k, v)
+        else:
+            assert abs(v - ref) <= tol.get(k, 2e-6) * max(abs(ref), 1e-3) + 1e-9, (tag, k, v, ref)
+
+
+def test_quality_metrics_fullsize_properties(dev):
+    """At the training size (16 x 512 x 512) through properties: identical tensors -> mse 0 / psnr inf / ssim 1; an all-valid
+    mask -> empty band -> boundary metrics 0 (metrics.py:93-98); symmetric in (pred, target) for mse / l1 / ssim;
+    deterministic run to run."""
+    from tg_hip import ops as O
+    g = torch.Generator().manual_seed(4)
+    a = torch.rand(16, 1, 512, 512, generator=g).to(dev)
+    b_ = (a + 0.05 * torch.randn(16, 1, 512, 512, generator=g).to(dev)).clamp(0, 1)
+    holes = (torch.rand(16, 1, 512, 512, generator=g) > 0.2).float().to(dev)
+    same = dict(zip(O.QUALITY_KEYS, O.quality_metrics(a, a, holes).tolist()))
+    assert same["mse"] == 0 and same["psnr"] == float("inf") and abs(same["ssim"] - 1) < 1e-6 and same["boundary_mse"] == 0
+    ones = dict(zip(O.QUALITY_KEYS, O.quality_metrics(a, b_, torch.ones_like(a)).tolist()))
+    assert ones["boundary_sum"] == 0 and ones["boundary_mse"] == ones["boundary_psnr"] == ones["boundary_gradient_diff"] == 0
+    q1, q2 = O.quality_metrics(a, b_, holes), O.quality_metrics(b_, a, holes)
+    assert torch.equal(q1, O.quality_metrics(a, b_, holes))
+    for i in (0, 2, 3, 5):
+        assert abs(float(q1[i]) - float(q2[i])) <= 1e-6 * abs(float(q1[i]))
+    assert abs(float(q1[4]) ** 2 - float(q1[0])) <= 1e-6 * float(q1[0])            # l2 = sqrt(mse)
+
+
+@pytest.mark.parametrize("tag", ["v2_128", "v1_256"])
+def test_validation_step_golden(dev, tag):
+    """validation_step (train.py:278-301) on the HIP engines: (i) against the CPU oracle on IDENTICAL weights -- tight;
+    (ii) against the reference fixture after one HIP train step -- the Adam update's +-lr sign noise separates the two
+    fp32 trajectories, so that comparison carries a drift tolerance; D's BatchNorm statistics move (D stays in train mode)."""
+    from tests import golden_util as GU
+    from mvp_gan.src.models import Discriminator, PConvUNet
+    from mvp_gan.src.train import train_step, validation_step
+    from mvp_gan.src.utils.losses import InpaintingLoss
+    from oracle import terragan_oracle as Orc
+    gold = GU.load("validation")
+    b, size = [int(v) for v in gold[f"{tag}/cfg"]]
+    torch.manual_seed(0)
+    G, D = PConvUNet(), Discriminator()
+    crit = InpaintingLoss(0.1, 0.1, device=torch.device("cpu"))
+    vp = {k: v.detach().clone() for k, v in crit.vgg_layers.state_dict().items()}
+    G, D, crit = G.to(dev), D.to(dev), crit.to(dev)
+    oG, oD = torch.optim.Adam(G.parameters(), lr=2e-4), torch.optim.Adam(D.parameters(), lr=2e-4)
+    real, mask = Orc.synth_batch(b, size, 70)
+    train_step(G, D, crit, oG, oD, real.to(dev), mask.to(dev))
+    gp, dp = _oracle_params(G), _oracle_params(D)                  # identical weights + running statistics for the oracle
+    G.eval()
+    vreal, vmask = Orc.synth_batch(b, size, 71)
+    vg, vd = validation_step(G, D, crit, vreal.to(dev), vmask.to(dev))
+    og, od, _gen = Orc.validation_losses(gp, dp, vp, vreal, vmask)
+    assert abs(float(vg) - float(og)) <= 5e-6 * abs(float(og)), (float(vg), float(og))
+    assert abs(float(vd) - float(od)) <= 5e-6 * abs(float(od)), (float(vd), float(od))
+    for k, v in D.state_dict().items():
+        if "running" in k:
+            assert torch.allclose(v.cpu(), dp[k], rtol=1e-5, atol=1e-6), k
+    assert int(D.model[3].num_batches_tracked) == int(gold[f"{tag}/d_nbt"]) == 5
+    for got, key in ((vg, "val_g_loss"), (vd, "val_d_loss")):
+        ref = float(gold[f"{tag}/{key}"])
+        assert abs(float(got) - ref) <= 5e-4 * abs(ref), (key, float(got), ref)
+
+
+def _png_dataset(root, n, hw=(100, 90), seed=3):
+    rng = np.random.default_rng(seed)
+    (root / "img").mkdir(parents=True)
+    (root / "msk").mkdir(parents=True)
+    for i in range(n):
+        Image.fromarray(rng.integers(0, 256, hw, dtype=np.uint8), mode="L").save(root / "img" / f"t{i:02d}.png")
+        m = np.full(hw, 255, np.uint8)
+        m[10 + 3 * i:50, 20:60 + i] = 0
+        m[70:80, 5:15] = rng.integers(0, 3, (10, 10), dtype=np.uint8)          # 1s and 2s: "> 0" is not "== 255"
+        Image.fromarray(m, mode="L").save(root / "msk" / f"t{i:02d}.png")
+
+
+def test_shard_loader_bit_exact(dev, tmp_path):
+    """Pre-decoded uint8 shard + on-device /255 and binarise (tg_u8_to_tiles) against the PNG path (InpaintingDataset +
+    Resize + ToTensor + `> 0` after the resize, dataset.py:24-37): every batch bit-identical, ragged last batch included."""
+    from torch.utils.data import DataLoader
+    from mvp_gan.src.utils.dataset import InpaintingDataset, resize_to_tensor
+    from mvp_gan.src.utils.shard_dataset import ShardLoader, build_shard, is_shard
+    _png_dataset(tmp_path, 7)
+    size = (128, 112)
+    shard = build_shard(tmp_path / "img", tmp_path / "msk", tmp_path / "shard", size)
+    assert is_shard(str(shard)) and not is_shard(str(tmp_path / "img"))
+    ref = DataLoader(InpaintingDataset(tmp_path / "img", tmp_path / "msk", transform=resize_to_tensor(size)), batch_size=3,
+                     shuffle=False)
+    mine = ShardLoader(str(shard), 3, shuffle=False, device=dev)
+    assert len(mine) == len(ref) == 3
+    for a, b_ in zip(mine, ref):
+        assert a["image"].shape == b_["image"].shape and a["image"].is_cuda
+        assert torch.equal(a["image"].cpu(), b_["image"]) and torch.equal(a["mask"].cpu(), b_["mask"])
+    # shuffled epochs draw every sample exactly once
+    sh = ShardLoader(str(shard), 4, shuffle=True, device=dev, seed=1)
+    assert sorted(sh.order()) == list(range(7))
+
+
+def test_train_from_shard_matches_png_path(dev, tmp_path):
+    """train() end to end from a shard directory equals train() from the PNG directories it was built from (same seeds,
+    shuffle off via a 1-batch epoch): identical checkpoints."""
+    from mvp_gan.src.train import train
+    from mvp_gan.src.utils.shard_dataset import build_shard
+    _png_dataset(tmp_path, 2)
+    shard = build_shard(tmp_path / "img", tmp_path / "msk", tmp_path / "shard", (128, 128))
+    cfg = {"training": {"batch_size": 2, "learning_rate": 2e-4, "epochs": 1, "loss_weights": {"perceptual": 0.1, "tv": 0.1}}}
+    outs = []
+    for src, name in (((tmp_path / "img", tmp_path / "msk"), "png"), ((shard, None), "shard")):
+        torch.manual_seed(0)
+        ck = tmp_path / f"{name}.pth"
+        train(src[0], src[1], checkpoint_path=ck, config=cfg, img_size=(128, 128))
+        outs.append(torch.load(ck, map_location="cpu", weights_only=False))
+    a, b_ = outs
+    assert sorted(a["generator_state_dict"]) == sorted(b_["generator_state_dict"])
+    # a 2-sample batch is the same SET either way; its order may differ (DataLoader shuffle vs ShardLoader shuffle), and
+    # BatchNorm / mean losses are permutation invariant up to fp32 summation order
+    assert abs(a["g_loss"] - b_["g_loss"]) <= 1e-5 * abs(a["g_loss"])
+
+
+def test_human_guided_trainer_train_loop(dev, tmp_path):
+    """HumanGuidedTrainer.train() itself (human_guided_trainer.py:44-262) at the reference's shape -- batch 5 of 512x512
+    (config.yaml:13, direct_match_dataset.py:41-43) -- for 2 epochs on a synthetic (image, system mask, human mask) triple
+    dataset: per-epoch and best checkpoints with the reference's keys (:189-195), tracker calls, return dictionary."""
+    from mvp_gan.src.models import PConvUNet
+    from mvp_gan.src.training import HumanGuidedTrainer
+    from oracle import terragan_oracle as Orc
+
+    class Triples(torch.utils.data.Dataset):
+        def __init__(self):
+            self.img, self.msk = Orc.synth_batch(5, 512, 41)
+            _, hm = Orc.synth_batch(5, 512, 42)
+            self.human = (1 - hm) * 255.0
+
+        def __len__(self):
+            return 5
+
+        def __getitem__(self, i):
+            return {"image": self.img[i], "mask": self.msk[i], "human_mask": self.human[i]}
+
+    class Tracker:
+        def __init__(self):
+            self.batches, self.metrics, self.models = 0, [], 0
+
+        def log_training_batch(self, **kw):
+            self.batches += 1
+
+        def log_metrics(self, metrics, step=None):
+            self.metrics.append(metrics)
+
+        def log_model(self, *a, **k):
+            self.models += 1
+
+    cfg = {"training": {"loss_weights": {"perceptual": 0.1, "tv": 0.1, "boundary": 0.5}, "log_interval": 1,
+                        "modes": {"human_guided": {"human_feedback_weight": 0.3, "base_loss_weight": 0.7,
+                                                   "learning_rate": 1e-4, "batch_size": 5}}}}
+    torch.manual_seed(0)
+    G = PConvUNet()
+    w0 = G.final.weight.detach().clone()
+    tr = Tracker()
+    res = HumanGuidedTrainer(cfg, tr).train(G, Triples(), 2, tmp_path)
+    assert set(res) == {"best_loss", "total_time", "final_epoch", "success"} and res["success"] and res["final_epoch"] == 1
+    assert np.isfinite(res["best_loss"]) and res["best_loss"] > 0
+    assert tr.batches == 2 and tr.models >= 1 and any("epoch.loss" in m for m in tr.metrics)
+    for name in ("generator_epoch_0.pth", "generator_epoch_1.pth", "best_model.pth"):
+        ck = torch.load(tmp_path / name, map_location="cpu", weights_only=False)
+        assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss", "config"}, name
+    assert len(ck["model_state_dict"]) == 114
+    assert not torch.equal(G.final.weight.detach().cpu(), w0)                      # it trained
+    G2 = PConvUNet()
+    G2.load_state_dict(ck["model_state_dict"])
+    st = ck["optimizer_state_dict"]["state"]
+    assert len(st) > 0 and int(next(iter(st.values()))["step"]) == 2

@@ -67,58 +67,100 @@ def _build(dev, seed=0):
     return G, D, crit, oG, oD
 
 
-def _check_weights(gold, prefix, G, D, lr_steps):
+ZERO_GRAD_BIASES = ("model.2.bias", "model.5.bias", "model.8.bias")
+SIGN_FLIPS = 2       # whole +-lr updates of near-zero-gradient elements that may differ between two fp32 evaluations
+                     # (the unc term is ONE fp32/fp64 pair's flip count, i.e. quantised in units of 2*lr itself)
+
+
+def _zero_grad_atol(unc, key):
+    """A conv bias that feeds BatchNorm has an analytically ZERO gradient: what any fp32 evaluation returns is rounding
+    noise of the reduction order (the oracle's own value is ~1e-9..1e-7).  Such tensors are held to noise level --
+    1e-5 of the gradient scale of the same conv's weight -- instead of to a relative bound on noise."""
+    name = key.rsplit("/", 1)[1]
+    if name.endswith("input_conv.bias") or name in ZERO_GRAD_BIASES:
+        return 1e-5 * float(unc[key[:-len("bias")] + "weight"][3])
+    return 1e-10
+
+
+def _check_weights(gold, prefix, G, D, lr_steps, unc, group="weights"):
+    """SURVEY 8c: |dw| <= 1e-3*lr*steps per element (summed over the tensor: the fixture stores sum and abs-sum);
+    analytically-zero-gradient tensors (conv biases that feed BatchNorm: fp32 sign noise through Adam's g/sqrt(v)) get
+    lr*steps per element.  `unc` adds K_UNC x the oracle's own fp32-vs-fp64 deviation of the same sums (Adam's first
+    updates are +-lr*sign(g): near-zero gradient elements flip whole updates in ANY fp32 evaluation)."""
     for pre, mod in [("G", G), ("D", D)]:
         for k, p_ in mod.named_parameters():
             ref = gold[f"{prefix}/w/{pre}.{k}"]
             n = p_.numel()
-            # |dw| <= 1e-3*lr*steps per element; analytically-zero-grad tensors (conv biases that feed
-            # BatchNorm: fp32 sign noise through Adam's g/sqrt(v)) get lr*steps
-            zero_grad_bias = k.endswith("input_conv.bias") or k in ("model.2.bias", "model.5.bias", "model.8.bias")
-            per = lr_steps if zero_grad_bias else 2e-2 * lr_steps
-            # + a few whole sign flips (2*lr each) of near-zero gradient elements in Adam's first steps
-            tol = per * n + 6 * lr_steps + 1e-6 * abs(ref[1])
-            assert abs(float(p_.detach().double().sum()) - ref[0]) <= tol, (prefix, pre, k, ref[0], tol)
-            assert abs(float(p_.detach().double().abs().sum()) - ref[1]) <= tol, (prefix, pre, k)
+            zero_grad_bias = k.endswith("input_conv.bias") or k in ZERO_GRAD_BIASES
+            per = lr_steps if zero_grad_bias else 1e-3 * lr_steps
+            u = unc.get(f"{prefix}/w/{pre}.{k}", (0.0, 0.0))              # frozen mask_conv ones: no entry, never move
+            for j, val in enumerate((float(p_.detach().double().sum()), float(p_.detach().double().abs().sum()))):
+                tol = per * n + GU.K_UNC * float(u[j]) + SIGN_FLIPS * 2 * lr_steps + 1e-6 * abs(ref[1])
+                err = abs(val - ref[j])
+                GU.record(group, f"{prefix}/w/{pre}.{k}[{'sum' if j == 0 else 'abssum'}]", err / tol, err, tol)
+                GU.expect(err <= tol, (prefix, pre, k, j, val, ref[j], tol))
 
 
 @pytest.mark.parametrize("tag", ["b4_128", "c1_256"])
 def test_train_steps_golden(dev, tag):
+    """Reference fixtures (tests/golden/steps.npz) at the STATED fp32 tolerances of SURVEY 8c -- outputs atol 2e-6, loss
+    scalars rtol 1e-6, gradients max|d| <= 1e-3*max|g|, weights 1e-3*lr*steps -- each widened only by K_UNC x the
+    reference arithmetic's own fp32-vs-fp64 deviation of that very quantity (tests/golden/steps_unc.npz, generated by
+    make_golden.py from the oracle): no flat loosening.  The measured worst err/bound ratios are written to
+    gpurun_out/parity/train_steps_<tag>.json and printed (pytest -s)."""
     from mvp_gan.src.train import train_step
     from oracle import terragan_oracle as Orc
-    gold = GU.load("steps")
+    gold, unc = GU.load("steps"), GU.load("steps_unc")
     b, size, nsteps, seed0 = [int(v) for v in gold[f"{tag}/cfg"]]
     G, D, crit, oG, oD = _build(dev)
     G.train(), D.train()
-    # c1_256 = BASELINE configs[0] (B=1, 256^2): stated tolerances.  b4_128 runs BN over 4 values/channel at enc7.
-    tight = tag == "c1_256"
+    GU.begin()
     for s in range(nsteps):
+        K = GU.K_UNC if s == 0 else GU.K_DRIFT
         real, mask = Orc.synth_batch(b, size, seed0 + s)
         out = train_step(G, D, crit, oG, oD, real.to(dev), mask.to(dev))
-        # Step 0 is the parity check proper.  From step 1 on, Adam's first updates are +-lr*sign(g) for EVERY
-        # parameter (v = g^2), so noise-dominated gradients flip whole +-lr updates (SURVEY §7 "analytically-zero
-        # gradients + Adam"); later steps are a chaotic-drift sanity check only.
+        # Step 0 is the parity check proper.  From step 1 on Adam's first updates are +-lr*sign(g) for EVERY parameter,
+        # so the trajectories of two fp32 evaluations separate; the unc term (the oracle's fp32 run against its fp64 run at
+        # the same step) measures exactly that and grows from ~1e-7 (step 0) to ~4e-4 (step 2) on the losses.
         for k in ["g_total", "g_loss", "g_adv", "d_loss", "real_loss", "fake_loss"]:
             ref = float(gold[f"{tag}/s{s}/{k}"])
-            rt = (5e-6 if tight else 2e-4) if s == 0 else 5e-3
-            assert abs(float(out[k]) - ref) <= rt * abs(ref) + 1e-7, (s, k, float(out[k]), ref)
+            bound = 1e-6 * abs(ref) + K * float(unc[f"{tag}/s{s}/{k}"]) + 1e-7
+            if s > 0:       # drift floor: ONE flipped +-lr update of a discriminator BatchNorm / bias element moves the
+                bound += 1e-4 * abs(ref)   # D losses by 1e-5..1e-4 relative, and the fp32/fp64 pair is a single draw of that
+            err = abs(float(out[k]) - ref)
+            GU.record(f"s{s}/losses", k, err / bound, err, bound)
+            GU.expect(err <= bound, (s, k, float(out[k]), ref, bound))
         if s == 0:
-            GU.check(gold, f"{tag}/s{s}/gen", out["gen"], atol=4e-6 if tight else 2e-4, rtol=0)
-        else:       # drift check: a handful of hole pixels move by ~1e-2 once +-lr sign flips have happened
+            bound = 2e-6 + K * float(unc[f"{tag}/s0/gen"])
+            ref = torch.from_numpy(gold[f"{tag}/s0/gen/full"]).double()
+            err = (out["gen"].detach().double().flatten().cpu() - ref).abs().max().item()
+            GU.record("s0/gen", "max abs", err / bound, err, bound)
+            GU.expect(err <= bound, f"{tag}/s0/gen max err {err:.3e} > {bound:.3e}")
+        else:       # a handful of hole pixels move once +-lr sign flips have happened: mean error vs the oracle's own drift
             ref = torch.from_numpy(gold[f"{tag}/s{s}/gen/full"]).double()
             mae = (out["gen"].detach().double().flatten().cpu() - ref).abs().mean().item()
-            assert mae <= 2e-4, f"{tag}/s{s}/gen mean abs err {mae:.3e}"
+            bound = 2e-6 + K * float(unc[f"{tag}/s{s}/gen_mean"])
+            GU.record(f"s{s}/gen", "mean abs", mae / bound, mae, bound)
+            GU.expect(mae <= bound, f"{tag}/s{s}/gen mean abs err {mae:.3e} > {bound:.3e}")
         if s == 0:
             for k, p_ in G.named_parameters():
                 if p_.requires_grad:
-                    GU.check(gold, f"{tag}/s0/ggrad/{k}", p_.grad, atol=1e-5, rtol=2e-2 if tight else 5e-2, scale_by_max=True)
+                    key = f"{tag}/s0/ggrad/{k}"
+                    GU.check_unc(gold, unc, key, p_.grad, "s0/ggrad", atol=_zero_grad_atol(unc, key))
             for k, p_ in D.named_parameters():
-                GU.check(gold, f"{tag}/s0/dgrad/{k}", p_.grad, atol=5e-5, rtol=5e-3 if tight else 5e-2, scale_by_max=True)
+                key = f"{tag}/s0/dgrad/{k}"
+                GU.check_unc(gold, unc, key, p_.grad, "s0/dgrad", atol=_zero_grad_atol(unc, key))
         if s in (0, nsteps - 1):
-            _check_weights(gold, f"{tag}/s{s}", G, D, 2e-4 * (s + 1))
+            _check_weights(gold, f"{tag}/s{s}", G, D, 2e-4 * (s + 1), unc, group=f"s{s}/weights")
             for k, buf in list(G.named_buffers()) + list(D.named_buffers()):
                 if "running" in k and k.split(".")[0] in ("enc1", "enc7", "dec1", "model"):
-                    GU.check(gold, f"{tag}/s{s}/buf/{k}", buf, atol=1e-4 if s == 0 else 2e-2, rtol=1e-3)
+                    key = f"{tag}/s{s}/buf/{k}"
+                    ref = torch.from_numpy(gold[key + "/full"]).double()
+                    err = (buf.detach().double().flatten().cpu() - ref).abs().max().item()
+                    bound = 1e-6 + 1e-5 * float(ref.abs().max()) + K * float(unc[key])
+                    GU.record(f"s{s}/bn_running", k, err / bound, err, bound)
+                    GU.expect(err <= bound, (key, err, bound))
+    GU.finish(f"train_steps_{tag}")
     assert int(D.model[3].num_batches_tracked) == 3 * nsteps        # D's BN sees 3 passes per step (App. A #8)
     st = oG.state[G.enc1.input_conv.weight]
     assert int(st["step"]) == nsteps and st["exp_avg"].shape == G.enc1.input_conv.weight.shape
@@ -196,15 +238,20 @@ class _BCE(torch.autograd.Function):
         return dz, None
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, backend="gloo"):
     import os
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)     # gloo moves the CUDA buffers through the host
+    if backend == "nccl":                                             # RCCL: one GPU per rank
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dev = torch.device("cuda:0")
+        dist.init_process_group("gloo", rank=rank, world_size=world)  # gloo moves the CUDA buffers through the host
     from mvp_gan.src.train import train_step
     from oracle import terragan_oracle as Orc
     from tg_hip.dist import GradSync
-    dev = torch.device("cuda:0")
     gold = GU.load("steps")
     n, b, size = [int(v) for v in gold["dp2_128/cfg"]]
     G, D, crit, oG, oD = _build(dev)
@@ -216,16 +263,21 @@ def _dp_worker(rank, world, port, q):
         res["w"] = {f"{pre}.{k}": (float(p_.double().sum()), float(p_.double().abs().sum()), p_.numel())
                     for pre, mod in (("G", G), ("D", D)) for k, p_ in mod.named_parameters()}
         res["ggrad"] = {k: p_.grad.detach().cpu().numpy().copy() for k, p_ in G.named_parameters()
-                        if p_.grad is not None and p_.numel() <= 64}
+                        if p_.grad is not None and p_.numel() <= 64}       # (sum over ranks; the fixture holds the mean)
     q.put((rank, res))
     dist.destroy_process_group()
 
 
-def test_dp2_train_step_golden(dev):
-    """2 ranks (both on this GPU, gloo transport) run one data-parallel train step through GradSync; losses per rank,
-    averaged gradients and post-Adam weights must match the reference's 2-micro-batch emulation."""
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_dp2_train_step_golden(dev, backend):
+    """2 ranks run one data-parallel train step through GradSync; losses per rank, averaged gradients and post-Adam
+    weights must match the reference's 2-micro-batch emulation.  gloo: both ranks on this GPU, buffers moved
+    through the host (runs on a 1-GPU box); nccl: the real RCCL transport, one GPU per rank -- skipped when the box has
+    fewer than two GPUs."""
     import socket
     import torch.multiprocessing as mp
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL test needs >= 2 GPUs")
     gold = GU.load("steps")
     s_ = socket.socket()
     s_.bind(("127.0.0.1", 0))
@@ -233,27 +285,55 @@ def test_dp2_train_step_golden(dev):
     s_.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p_ in procs:
         p_.start()
-    res = dict(q.get(timeout=300) for _ in range(2))
-    for p_ in procs:
-        p_.join(timeout=120)
-        assert p_.exitcode == 0
+    res = _collect(procs, q, 2)
+    unc = GU.load("steps_unc")
+    GU.begin()
     for r in range(2):
         for k in ("g_total", "d_loss"):
             ref = float(gold[f"dp2_128/r{r}/{k}"])
-            assert abs(res[r][k] - ref) <= 2e-4 * abs(ref) + 1e-7, (r, k, res[r][k], ref)
+            bound = 1e-6 * abs(ref) + GU.K_UNC * float(unc[f"dp2_128/r{r}/{k}"]) + 1e-7
+            err = abs(res[r][k] - ref)
+            GU.record("dp2/losses", f"r{r}/{k}", err / bound, err, bound)
+            GU.expect(err <= bound, (r, k, res[r][k], ref, bound))
     for k, g in res[0]["ggrad"].items():           # small tensors are stored in full: averaged generator gradients
         key = f"dp2_128/ggrad/{k}"
-        if key + "/full" in gold and not k.endswith("input_conv.bias"):
-            ref = gold[key + "/full"]
-            assert np.abs(g.reshape(-1) * 0.5 - ref).max() <= 5e-2 * np.abs(ref).max() + 1e-5, k
+        if key + "/full" in gold:
+            GU.check_unc(gold, unc, key, torch.from_numpy(g) * 0.5, "dp2/ggrad", atol=_zero_grad_atol(unc, key))
     lr = 2e-4
     for name, (sm, ab, n) in res[0]["w"].items():
         ref = gold[f"dp2_128/w/{name}"]
-        per = lr if (name.endswith("input_conv.bias") or name in ("D.model.2.bias", "D.model.5.bias", "D.model.8.bias")) else 2e-2 * lr
-        assert abs(sm - ref[0]) <= per * n + 6 * lr + 1e-6 * abs(ref[1]), (name, sm, ref[0])
+        zero = name.endswith("input_conv.bias") or name in tuple("D." + z for z in ZERO_GRAD_BIASES)
+        u = unc.get(f"dp2_128/w/{name}", (0.0, 0.0))
+        tol = (lr if zero else 1e-3 * lr) * n + GU.K_UNC * float(u[0]) + SIGN_FLIPS * 2 * lr + 1e-6 * abs(ref[1])
+        GU.record("dp2/weights", name, abs(sm - ref[0]) / tol, abs(sm - ref[0]), tol)
+        GU.expect(abs(sm - ref[0]) <= tol, (name, sm, ref[0], tol))
+    GU.finish(f"dp2_128_{backend}")
+
+
+def _collect(procs, q, n, timeout=600):
+    """Results of `n` worker processes; a worker that dies is reported at once (its exit code) instead of blocking the
+    parent on the queue."""
+    import queue as _queue
+    import time as _time
+    res, t0 = {}, _time.time()
+    while len(res) < n:
+        try:
+            rank, r = q.get(timeout=2)
+            res[rank] = r
+        except _queue.Empty:
+            dead = [(i, p_.exitcode) for i, p_ in enumerate(procs) if p_.exitcode not in (None, 0)]
+            if dead or _time.time() - t0 > timeout:
+                for p_ in procs:
+                    if p_.is_alive():
+                        p_.kill()
+                raise AssertionError(f"DP workers failed: exit codes {dead}" if dead else "DP workers timed out")
+    for p_ in procs:
+        p_.join(timeout=120)
+        assert p_.exitcode == 0, p_.exitcode
+    return res
 
 
 def test_dp8_virtual_ranks_golden(dev):
@@ -311,18 +391,26 @@ def test_dp8_virtual_ranks_golden(dev):
         t.join(timeout=600)
     assert not errs, errs
     torch.cuda.synchronize()
+    unc = GU.load("steps_unc")
+    GU.begin()
     for r in range(world):
         for k in ("g_total", "d_loss"):
             ref = float(gold[f"dp8_128/r{r}/{k}"])
-            assert abs(res[r][k] - ref) <= 2e-4 * abs(ref) + 1e-7, (r, k, res[r][k], ref)
+            bound = 1e-6 * abs(ref) + GU.K_UNC * float(unc[f"dp8_128/r{r}/{k}"]) + 1e-7
+            err = abs(res[r][k] - ref)
+            GU.record("dp8/losses", f"r{r}/{k}", err / bound, err, bound)
+            GU.expect(err <= bound, (r, k, res[r][k], ref, bound))
     G0, D0 = reps[0][0], reps[0][1]
     for k, p_ in G0.named_parameters():     # p.grad holds the SUM over ranks; the fixture the mean
         key = f"dp8_128/ggrad/{k}"
-        if p_.grad is not None and key + "/full" in gold and not k.endswith("input_conv.bias"):
-            ref = gold[key + "/full"]
-            got = p_.grad.detach().cpu().numpy().reshape(-1) / world
-            assert np.abs(got - ref).max() <= 5e-2 * np.abs(ref).max() + 1e-5, k
-    _check_weights(gold, "dp8_128", G0, D0, 2e-4)
+        if p_.grad is not None and key in unc:
+            GU.check_unc(gold, unc, key, p_.grad.detach() / world, "dp8/ggrad", atol=_zero_grad_atol(unc, key))
+    for k, p_ in D0.named_parameters():
+        key = f"dp8_128/dgrad/{k}"
+        if p_.grad is not None and key in unc:
+            GU.check_unc(gold, unc, key, p_.grad.detach() / world, "dp8/dgrad", atol=_zero_grad_atol(unc, key))
+    _check_weights(gold, "dp8_128", G0, D0, 2e-4, unc, group="dp8/weights")
+    GU.finish("dp8_128")
     for r in range(1, world):               # replicas stay bit-identical: the DP invariant
         for (k, a), (_k, c) in zip(list(G0.state_dict().items()) + list(D0.state_dict().items()),
                                    list(reps[r][0].state_dict().items()) + list(reps[r][1].state_dict().items())):
@@ -347,3 +435,149 @@ def test_activation_checkpointing_is_exact(dev):
     assert res[0][1] == res[1][1]
     for a, b in zip(res[0][0], res[1][0]):
         assert torch.equal(a, b)
+
+
+def test_config5_fullsize_checkpointed_step(dev):
+    """BASELINE config 5's per-GPU shape -- 1024x1024, batch 4, activation checkpointing -- through size-independent
+    properties (the CPU oracle would need ~10 minutes here): the checkpointed step is bit-identical to the plain one
+    (losses, generator output, every weight after two Adam steps), bitwise reproducible run to run, valid pixels are
+    copied exactly (generator.py:60-62), and the peak HBM footprint drops."""
+    from mvp_gan.src.train import train_step
+    from oracle import terragan_oracle as Orc
+    real, mask = Orc.synth_batch(4, 1024, 3001)
+    real, mask = real.to(dev), mask.to(dev)
+    res = {}
+    for name, ck in (("plain", False), ("ckpt", True), ("ckpt2", True)):
+        G, D, crit, oG, oD = _build(dev)
+        G.activation_checkpointing = ck
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        for _s in range(2):
+            out = train_step(G, D, crit, oG, oD, real, mask)
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() - base
+        res[name] = ([p_.detach().clone() for p_ in list(G.parameters()) + list(D.parameters())], out["gen"].clone(),
+                     float(out["g_total"]), float(out["d_loss"]), peak)
+        del G, D, crit, oG, oD, out
+    for other in ("ckpt", "ckpt2"):
+        assert res["plain"][2] == res[other][2] and res["plain"][3] == res[other][3], (res["plain"][2:4], res[other][2:4])
+        assert torch.equal(res["plain"][1], res[other][1])
+        for a, b in zip(res["plain"][0], res[other][0]):
+            assert torch.equal(a, b)
+    gen = res["ckpt"][1]
+    valid = mask > 0
+    assert torch.equal(gen[valid], (real * mask)[valid]) and bool(torch.isfinite(gen).all())
+    print(f"\nconfig 5 peak HBM over the step: plain {res['plain'][4] / 2**30:.2f} GiB, checkpointed {res['ckpt'][4] / 2**30:.2f} GiB")
+    assert res["ckpt"][4] < 0.85 * res["plain"][4], (res["plain"][4], res["ckpt"][4])
+
+
+def test_adam_state_from_reference_format_checkpoint(dev):
+    """Resuming from a reference-format checkpoint (main_pipeline.py:260-263): Optimizer.load_state_dict keeps the SAVED
+    strides of exp_avg / exp_avg_sq (contiguous OIHW) while the parameters here are channels_last.  hip_adam_step re-lays
+    the moments once; the update must equal torch.optim.Adam's own arithmetic on the same state."""
+    from mvp_gan.src.models import Discriminator
+    from mvp_gan.src.train import hip_adam_step
+    torch.manual_seed(5)
+    D = Discriminator().to(dev)
+    D(torch.rand(2, 1, 64, 64, device=dev))                  # first forward fixes the channels_last parameter layout
+    params = list(D.parameters())
+    g = torch.Generator().manual_seed(6)
+    grads0 = [torch.randn(p_.shape, generator=g) for p_ in params]
+    grads1 = [torch.randn(p_.shape, generator=g) for p_ in params]
+    # the "reference" side: contiguous CPU parameters, torch's own Adam, one step -> a state-dict with contiguous moments
+    ref_params = [torch.nn.Parameter(p_.detach().cpu().contiguous().clone()) for p_ in params]
+    ref_opt = torch.optim.Adam(ref_params, lr=2e-4)
+    for p_, g_ in zip(ref_params, grads0):
+        p_.grad = g_.clone()
+    ref_opt.step()
+    import copy
+    sd = copy.deepcopy(ref_opt.state_dict())       # (load_state_dict would otherwise share the `step` tensors)
+    assert sd["state"][2]["exp_avg"].is_contiguous()
+    with torch.no_grad():
+        for p_, r_ in zip(params, ref_params):
+            p_.copy_(r_.to(dev))
+    opt = torch.optim.Adam(params, lr=2e-4)
+    opt.load_state_dict(sd)
+    w = D.model[2].weight
+    assert not (opt.state[w]["exp_avg"].stride() == w.stride())           # the mismatch this test is about
+    for p_, g_ in zip(params, grads1):
+        p_.grad = torch.empty_like(p_).copy_(g_.to(dev))
+    hip_adam_step(opt)
+    for p_, g_ in zip(ref_params, grads1):
+        p_.grad = g_.clone()
+    ref_opt.step()
+    torch.cuda.synchronize()
+    assert opt.state[w]["exp_avg"].stride() == w.stride() and int(opt.state[w]["step"]) == 2
+    for p_, r_ in zip(params, ref_params):
+        assert torch.allclose(p_.detach().cpu(), r_.detach(), rtol=1e-6, atol=1e-7)
+        assert torch.allclose(opt.state[p_]["exp_avg"].cpu(), ref_opt.state[r_]["exp_avg"], rtol=1e-6, atol=1e-9)
+        assert torch.allclose(opt.state[p_]["exp_avg_sq"].cpu(), ref_opt.state[r_]["exp_avg_sq"], rtol=1e-6, atol=1e-12)
+
+
+def _train_worker(rank, world, port, q, root):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import hashlib
+    from pathlib import Path
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mvp_gan.src.models import Discriminator, PConvUNet
+    from mvp_gan.src.train import train
+    from tg_hip.dist import GradSync
+    dev = torch.device("cuda:0")
+    root = Path(root)
+    torch.manual_seed(100 + rank)                    # DIFFERENT initial weights per rank: train() must broadcast rank 0's
+    G, D = PConvUNet().to(dev), Discriminator().to(dev)
+    cfg = {"training": {"batch_size": 2, "learning_rate": 2e-4, "epochs": 2, "checkpoint_interval": 1, "seed": 3,
+                        "loss_weights": {"perceptual": 0.1, "tv": 0.1}}}
+    seen = []
+
+    class Tracker:
+        def log_training_batch(self, **kw):
+            seen.append(kw["step"])
+
+        def log_metrics(self, *a, **k):
+            pass
+
+    ck = root / f"best_rank{rank}.pth"               # per-rank name: proves that only rank 0 writes
+    res = train(root / "img", root / "msk", generator=G, discriminator=D, checkpoint_path=ck, config=cfg,
+                experiment_tracker=Tracker(), grad_sync=GradSync(world, bucket_mb=8.0), img_size=(128, 128))
+    torch.cuda.synchronize()
+    h = hashlib.sha256()
+    for p_ in list(G.parameters()) + list(D.parameters()):
+        h.update(p_.detach().cpu().contiguous().numpy().tobytes())
+    q.put((rank, {"hash": h.hexdigest(), "final_epoch": res["final_epoch"], "tracked": len(seen), "ckpt": ck.exists()}))
+    dist.destroy_process_group()
+
+
+def test_train_data_parallel_two_ranks(dev, tmp_path):
+    """train(..., grad_sync=...) as a data-parallel loop (2 ranks on this GPU, gloo): rank 0's initial weights are
+    broadcast, every rank trains on its own shard, replicas end bit-identical, checkpoints and tracker records come from
+    rank 0 only."""
+    import socket
+    import torch.multiprocessing as mp
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    (tmp_path / "img").mkdir()
+    (tmp_path / "msk").mkdir()
+    for i in range(8):                               # 4 per rank = 2 batches of 2 (a batch of 1 has no BatchNorm statistics at 1x1)
+        Image.fromarray(rng.integers(0, 256, (96, 96), dtype=np.uint8), mode="L").save(tmp_path / "img" / f"t{i}.png")
+        m = np.full((96, 96), 255, np.uint8)
+        m[10 + 5 * i:60, 30:70] = 0
+        Image.fromarray(m, mode="L").save(tmp_path / "msk" / f"t{i}.png")
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = _collect(procs, q, 2)
+    assert res[0]["hash"] == res[1]["hash"]                          # replicas identical after 2 epochs x 2 batches
+    assert res[0]["final_epoch"] == res[1]["final_epoch"] == 1
+    assert res[0]["ckpt"] and not res[1]["ckpt"] and res[0]["tracked"] > 0 and res[1]["tracked"] == 0
+    assert (tmp_path / "checkpoint_epoch_0.pth").exists()

@@ -186,3 +186,44 @@ def test_dp_emulation(fixture, tag):
             ref = float(gold[f"{tag}/r{r}/{k}"])
             assert abs(float(scal[r][k]) - ref) <= 2e-6 * abs(ref) + 1e-7, (r, k)
     _check_weights(gold, tag, st, 2e-4)
+
+
+QUALITY_CASES = ["q48x40", "q64", "q33x70", "qones", "qsame"]
+
+
+@pytest.mark.parametrize("tag", QUALITY_CASES)
+def test_quality_metrics(tag):
+    """Oracle restatement of the logged metrics against the reference's own evaluation/metrics.py (fixture metrics.npz:
+    blocks / 30 % holes / border masks, an empty-band case and identical tensors -> PSNR inf)."""
+    gold = GU.load("metrics")
+    pred, tgt = torch.from_numpy(gold[f"{tag}/pred"]), torch.from_numpy(gold[f"{tag}/target"])
+    m = torch.from_numpy(gold[f"{tag}/mask"]).float()
+    got = dict(O.boundary_quality(pred, tgt, m))
+    got["psnr"], got["ssim"] = O.psnr(pred, tgt), O.ssim(pred, tgt)
+    got["l1_distance"], got["l2_distance"] = O.l1_l2(pred, tgt)
+    for k, v in got.items():
+        ref = float(gold[f"{tag}/{k}"])
+        if ref == float("inf"):
+            assert v == float("inf"), (tag, k, v)
+        else:
+            assert abs(v - ref) <= 1e-6 * abs(ref) + 1e-9, (tag, k, v, ref)
+
+
+@pytest.mark.parametrize("tag", ["v2_128", "v1_256"])
+def test_validation_pass(tag):
+    """train.py:278-301 (generator in eval mode, discriminator left in train mode) after one train step."""
+    gold = GU.load("validation")
+    b, size = [int(v) for v in gold[f"{tag}/cfg"]]
+    st = O.TrainState(0)
+    real, mask = O.synth_batch(b, size, 70)
+    O.train_step(st, real, mask)
+    vreal, vmask = O.synth_batch(b, size, 71)
+    g, d, gen = O.validation_losses(st.gp, st.dp, st.vp, vreal, vmask)
+    for got, key in ((g, "val_g_loss"), (d, "val_d_loss")):
+        ref = float(gold[f"{tag}/{key}"])
+        assert abs(float(got) - ref) <= 2e-6 * abs(ref) + 1e-7, (key, float(got), ref)
+    GU.check(gold, f"{tag}/gen", gen, atol=2e-6, rtol=0)
+    for k, v in st.dp.items():
+        if "running" in k:
+            GU.check(gold, f"{tag}/dbuf/{k}", v, atol=1e-6, rtol=1e-5)
+    assert int(st.dp["model.3.num_batches_tracked"]) == int(gold[f"{tag}/d_nbt"]) == 5    # 3 (train step) + 2 (validation)

@@ -73,6 +73,23 @@ int tg_conv_dgrad_gated(const TgConv* g, const float* dy, const float* w, const 
                         const float* x_act, int act, float slope, float* dx, float* ws,
                         size_t ws_bytes, tg_stream_t stream);
 
+/* Prepared weights.  The weight rearrangements inside tg_conv_fwd / tg_conv_dgrad (Winograd transform of the stride-1 3x3
+ * layers, the [Cin][kh][kw][Cout] transpose of the gather dgrads, the 3x3 x 4C regrouping of 5x5 stride-2 layers) depend
+ * on the weights only: a caller that keeps them once per optimiser step (once ever for the frozen VGG trunk of
+ * losses.py:31-34) saves ~45 small launches per train step.  tg_conv_wprep_bytes == 0: that (geometry, mode) runs on the
+ * raw weights.  The *_p entry points equal tg_conv_fwd / tg_conv_dgrad / tg_conv_dgrad_gated (x_act != NULL) when
+ * wprep == NULL; with wprep they skip the preparation and need no workspace room for it.  A prepared buffer is valid for
+ * the geometry (all TgConv fields but B) and mode it was made for, until the weights change. */
+enum { TG_WPREP_FWD = 0, TG_WPREP_DGRAD = 1 };
+size_t tg_conv_wprep_bytes(const TgConv* g, int mode);
+int tg_conv_wprep(const TgConv* g, int mode, const float* w, float* wprep, tg_stream_t stream);
+int tg_conv_fwd_p(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* wprep,
+                  const float* bias, const float* ratio, int act, float slope, float* y, float* ws,
+                  size_t ws_bytes, tg_stream_t stream);
+int tg_conv_dgrad_p(const TgConv* g, const float* dy, const float* w, const float* wprep, const float* in_mask,
+                    const float* x_act, int act, float slope, float* dx, int accumulate, float* ws,
+                    size_t ws_bytes, tg_stream_t stream);
+
 /* dw[Cout][k][k][Cin] = sum_pixels dy (x) (x (.) in_mask);  db[Cout] = sum_pixels dy (db may be NULL).
  * Deterministic: split-K partial slabs in ws, reduced in a fixed order. */
 size_t tg_conv_wgrad_ws_bytes(const TgConv* g);

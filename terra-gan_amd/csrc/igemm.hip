@@ -1110,29 +1110,63 @@ extern "C" size_t tg_conv_fwd_ws_bytes(const TgConv* g) {
     return base;
 }
 
-extern "C" int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* bias,
-                           const float* ratio, int act, float slope, float* y, float* ws, size_t ws_bytes,
-                           tg_stream_t stream) {
+// Prepared weights.  Every weight rearrangement the conv kernels need (the Winograd transform U = G g Gt of the stride-1 3x3
+// layers, the [Cin][taps][Cout] transpose of the gather dgrads, the 3x3 x 4C regrouping of the 5x5 stride-2 layers)
+// depends on the weights only, so the caller may have it computed ONCE per optimiser step (once ever for the frozen VGG
+// trunk) by tg_conv_wprep and hand it to tg_conv_fwd_p / tg_conv_dgrad_p.  `prep`: 0 = none given (prepare per call in
+// the workspace, the tg_conv_fwd / tg_conv_dgrad behaviour), 1 = `wprep` is ready, -1 = fill `wprep` and return.
+static bool wino_fwd_geom_ok(const TgConv* g) {
+    static const bool off = getenv("TG_NO_WINO") != nullptr;
+    return !off && g->precision != TG_PREC_BF16 && g->k == 3 && g->stride == 1 && (g->Cin % 8) == 0 && (g->Cout % WINO_BN) == 0 &&
+           g->Ho >= 16 && g->Wo >= 16;
+}
+static bool wino_dgrad_geom_ok(const TgConv* g) {
+    static const bool off = getenv("TG_NO_WINO") != nullptr;
+    return !off && g->precision != TG_PREC_BF16 && g->k == 3 && g->stride == 1 && (g->Cout % 8) == 0 && (g->Cin % WINO_BN) == 0 &&
+           g->H >= 16 && g->W >= 16;
+}
+static size_t dgrad_wt_floats(const TgConv* g);
+extern "C" size_t tg_conv_wprep_bytes(const TgConv* g, int mode) {
+    if (!g) return 0;
+    if (s2d_ok(g)) {
+        const TgConv g2 = s2d_geom(g);
+        return s2d_w_floats(g) * sizeof(float) + tg_conv_wprep_bytes(&g2, mode);
+    }
+    if (mode == TG_WPREP_FWD) return wino_fwd_geom_ok(g) ? conv_wino_floats(g) * sizeof(float) : 0;
+    if (mode == TG_WPREP_DGRAD) return dgrad_wt_floats(g) * sizeof(float);
+    return 0;
+}
+
+static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, const float* w, float* wprep, int prep,
+                         const float* bias, const float* ratio, int act, float slope, float* y, float* ws, size_t ws_bytes,
+                         tg_stream_t stream) {
     int rc = check_conv(g, "tg_conv_fwd");
     if (rc) return rc;
-    TG_REQUIRE(x && w && y, "tg_conv_fwd: null pointer");
-    TG_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), "tg_conv_fwd: pointers must be 16-byte aligned");
-    if (s2d_ok(g) && ws && aligned16(ws) && ws_bytes >= tg_conv_fwd_ws_bytes(g)) {
+    TG_REQUIRE(w && (prep < 0 || (x && y)), "tg_conv_fwd: null pointer");
+    TG_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && aligned16(wprep), "tg_conv_fwd: pointers must be 16-byte aligned");
+    TG_REQUIRE(prep == 0 || wprep != nullptr, "tg_conv_fwd: prepared weights expected");
+    const bool ws_ok = ws && aligned16(ws) && ws_bytes >= tg_conv_fwd_ws_bytes(g);
+    if (s2d_ok(g) && (prep < 0 || ws_ok)) {
         // 5x5 stride 2 -> 3x3 stride 1 over the space-to-depth input (see s2d_kernel)
         hipStream_t s = (hipStream_t)stream;
         const TgConv g2 = s2d_geom(g);
         float* x2 = ws;
-        float* w2 = ws + s2d_x_floats(g);
-        float* ws2 = w2 + s2d_w_floats(g);
-        hipLaunchKernelGGL(s2d_kernel, dim3(ew_grid((int64_t)g->B * g->H * g->W * (g->Cin / 4), 256)), dim3(256), 0, s, x, in_mask, x2,
-                           g->B, g->H, g->W, g->Cin);
-        TG_CHECK_LAUNCH("s2d_kernel");
-        hipLaunchKernelGGL(w5x5_s2d_kernel, dim3(ew_grid((int64_t)g->Cout * 36 * g->Cin, 256)), dim3(256), 0, s, w, w2, g->Cout, g->Cin, 1);
-        TG_CHECK_LAUNCH("w5x5_s2d_kernel");
+        float* w2 = prep ? wprep : ws + s2d_x_floats(g);
+        float* ws2 = ws ? ws + s2d_x_floats(g) + s2d_w_floats(g) : nullptr;
+        if (prep <= 0) {
+            hipLaunchKernelGGL(w5x5_s2d_kernel, dim3(ew_grid((int64_t)g->Cout * 36 * g->Cin, 256)), dim3(256), 0, s, w, w2, g->Cout, g->Cin, 1);
+            TG_CHECK_LAUNCH("w5x5_s2d_kernel");
+        }
+        if (prep >= 0) {
+            hipLaunchKernelGGL(s2d_kernel, dim3(ew_grid((int64_t)g->B * g->H * g->W * (g->Cin / 4), 256)), dim3(256), 0, s, x, in_mask, x2,
+                               g->B, g->H, g->W, g->Cin);
+            TG_CHECK_LAUNCH("s2d_kernel");
+        }
         AlgScale sc(25.0 / 36.0);
-        return tg_conv_fwd(&g2, x2, nullptr, w2, bias, ratio, act, slope, y, ws2,
-                           ws_bytes - (s2d_x_floats(g) + s2d_w_floats(g)) * sizeof(float), stream);
+        return conv_fwd_impl(&g2, x2, nullptr, w2, prep ? wprep + s2d_w_floats(g) : nullptr, prep, bias, ratio, act, slope, y, ws2,
+                             ws ? ws_bytes - (s2d_x_floats(g) + s2d_w_floats(g)) * sizeof(float) : 0, stream);
     }
+    TG_REQUIRE(!(s2d_ok(g) && prep > 0), "tg_conv_fwd: workspace too small for the prepared 5x5 stride-2 path");
     IGemmParams p = {};
     p.src = x; p.amask = in_mask; p.wmat = w; p.bias = bias; p.rowscale = ratio; p.dst = y; p.ws = ws;
     p.B = g->B; p.IH = g->H; p.IW = g->W; p.C = g->Cin;
@@ -1147,18 +1181,31 @@ extern "C" int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask
     p.T = (p.C % 4) ? cdiv(p.Ktot, 32) : p.TH * p.TW * p.nchunks;
     size_t ws_floats = ws ? ws_bytes / sizeof(float) : 0;
     const size_t uf = conv_wino_floats(g);
-    if (uf && ws_floats >= uf && aligned16(ws)) {         // transformed weights live at the head of the workspace
+    if (wino_fwd_geom_ok(g) && (prep || (ws_floats >= uf && aligned16(ws)))) {
+        // transformed weights: prepared by the caller, or at the head of the workspace
         p.w_raw = w; p.w_sn = (long)p.Kfull; p.w_sk = 1; p.w_stap = g->Cin;
-        p.wino_u = ws;
-        if (wino_ok(p)) {
+        p.wino_u = prep ? wprep : ws;
+        p.wino_ready = prep;
+        TG_REQUIRE(wino_ok(p), "tg_conv_fwd: internal: Winograd geometry predicate mismatch");
+        if (!prep) {
             p.ws = ws + uf;
             ws_floats -= uf;
-        } else {
-            p.wino_u = nullptr;
         }
     }
+    if (prep < 0 && !p.wino_u) return TG_OK;              // this layer runs on the raw weights: nothing to prepare
     plan_splits(p, ws_floats);
     return launch_igemm(p, (hipStream_t)stream, ws_floats);
+}
+extern "C" int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* bias,
+                           const float* ratio, int act, float slope, float* y, float* ws, size_t ws_bytes,
+                           tg_stream_t stream) {
+    return conv_fwd_impl(g, x, in_mask, w, nullptr, 0, bias, ratio, act, slope, y, ws, ws_bytes, stream);
+}
+extern "C" int tg_conv_fwd_p(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* wprep,
+                             const float* bias, const float* ratio, int act, float slope, float* y, float* ws, size_t ws_bytes,
+                             tg_stream_t stream) {
+    return conv_fwd_impl(g, x, in_mask, w, const_cast<float*>(wprep), wprep ? 1 : 0, bias, ratio, act, slope, y, ws, ws_bytes,
+                         stream);
 }
 
 // ---- dgrad ---------------------------------------------------------------------------------------
@@ -1194,51 +1241,79 @@ extern "C" size_t tg_conv_dgrad_ws_bytes(const TgConv* g) {
     return (wt + (want < cap ? want : cap)) * sizeof(float);
 }
 
-static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, const float* in_mask, float* dx, int accumulate,
-                           const float* gate, int gate_act, float gate_slope, float* ws, size_t ws_bytes, tg_stream_t stream);
+static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, float* wprep, int prep, const float* in_mask, float* dx,
+                           int accumulate, const float* gate, int gate_act, float gate_slope, float* ws, size_t ws_bytes,
+                           tg_stream_t stream);
 extern "C" int tg_conv_dgrad(const TgConv* g, const float* dy, const float* w, const float* in_mask, float* dx,
                              int accumulate, float* ws, size_t ws_bytes, tg_stream_t stream) {
-    return conv_dgrad_impl(g, dy, w, in_mask, dx, accumulate, nullptr, 0, 0.f, ws, ws_bytes, stream);
+    return conv_dgrad_impl(g, dy, w, nullptr, 0, in_mask, dx, accumulate, nullptr, 0, 0.f, ws, ws_bytes, stream);
 }
 extern "C" int tg_conv_dgrad_gated(const TgConv* g, const float* dy, const float* w, const float* in_mask, const float* x_act,
                                    int act, float slope, float* dx, float* ws, size_t ws_bytes, tg_stream_t stream) {
     TG_REQUIRE(x_act != nullptr && (act == TG_ACT_RELU || act == TG_ACT_LEAKY), "tg_conv_dgrad_gated: needs x_act and a ReLU/LeakyReLU");
-    return conv_dgrad_impl(g, dy, w, in_mask, dx, 0, x_act, act, slope, ws, ws_bytes, stream);
+    return conv_dgrad_impl(g, dy, w, nullptr, 0, in_mask, dx, 0, x_act, act, slope, ws, ws_bytes, stream);
 }
-static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, const float* in_mask, float* dx, int accumulate,
-                           const float* gate, int gate_act, float gate_slope, float* ws, size_t ws_bytes, tg_stream_t stream) {
+// x_act == NULL: plain dgrad (accumulate honoured); else the gated form (accumulate must be 0)
+extern "C" int tg_conv_dgrad_p(const TgConv* g, const float* dy, const float* w, const float* wprep, const float* in_mask,
+                               const float* x_act, int act, float slope, float* dx, int accumulate, float* ws, size_t ws_bytes,
+                               tg_stream_t stream) {
+    TG_REQUIRE(x_act == nullptr || ((act == TG_ACT_RELU || act == TG_ACT_LEAKY) && !accumulate),
+               "tg_conv_dgrad_p: a gated dgrad needs a ReLU/LeakyReLU and accumulate == 0");
+    // a gated dgrad of a 5x5 stride-2 layer does not take the space-to-depth path its prepared weights were laid out for
+    const bool usable = wprep != nullptr && !(x_act != nullptr && g && s2d_ok(g));
+    return conv_dgrad_impl(g, dy, w, usable ? const_cast<float*>(wprep) : nullptr, usable ? 1 : 0, in_mask, dx, accumulate, x_act,
+                           act, slope, ws, ws_bytes, stream);
+}
+extern "C" int tg_conv_wprep(const TgConv* g, int mode, const float* w, float* wprep, tg_stream_t stream) {
+    TG_REQUIRE(g && w && wprep, "tg_conv_wprep: null pointer");
+    TG_REQUIRE(mode == TG_WPREP_FWD || mode == TG_WPREP_DGRAD, "tg_conv_wprep: bad mode %d", mode);
+    TG_REQUIRE(tg_conv_wprep_bytes(g, mode) > 0, "tg_conv_wprep: this (geometry, mode) runs on the raw weights");
+    if (mode == TG_WPREP_FWD)
+        return conv_fwd_impl(g, nullptr, nullptr, w, wprep, -1, nullptr, nullptr, 0, 0.f, nullptr, nullptr, 0, stream);
+    return conv_dgrad_impl(g, nullptr, w, wprep, -1, nullptr, nullptr, 0, nullptr, 0, 0.f, nullptr, 0, stream);
+}
+static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, float* wprep, int prep, const float* in_mask, float* dx,
+                           int accumulate, const float* gate, int gate_act, float gate_slope, float* ws, size_t ws_bytes,
+                           tg_stream_t stream) {
     int rc = check_conv(g, "tg_conv_dgrad");
     if (rc) return rc;
-    TG_REQUIRE(dy && w && dx && ws, "tg_conv_dgrad: null pointer");
-    TG_REQUIRE(aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(ws), "tg_conv_dgrad: pointers must be 16-byte aligned");
-    if (s2d_ok(g) && gate == nullptr && ws_bytes >= tg_conv_dgrad_ws_bytes(g)) {
+    TG_REQUIRE(w && (prep < 0 || (dy && dx && ws)), "tg_conv_dgrad: null pointer");
+    TG_REQUIRE(aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(ws) && aligned16(wprep),
+               "tg_conv_dgrad: pointers must be 16-byte aligned");
+    TG_REQUIRE(prep == 0 || wprep != nullptr, "tg_conv_dgrad: prepared weights expected");
+    if (s2d_ok(g) && gate == nullptr && (prep < 0 || ws_bytes >= tg_conv_dgrad_ws_bytes(g))) {
         // dx2 = 3x3 stride-1 dgrad over the space-to-depth layout, then depth-to-space (+ mask, + accumulate)
         hipStream_t s2 = (hipStream_t)stream;
         const TgConv g2 = s2d_geom(g);
         float* dx2 = ws;
-        float* w2 = ws + s2d_x_floats(g);
-        float* wsr = w2 + s2d_w_floats(g);
-        hipLaunchKernelGGL(w5x5_s2d_kernel, dim3(ew_grid((int64_t)g->Cout * 36 * g->Cin, 256)), dim3(256), 0, s2, w, w2, g->Cout, g->Cin, 1);
-        TG_CHECK_LAUNCH("w5x5_s2d_kernel");
+        float* w2 = prep ? wprep : ws + s2d_x_floats(g);
+        float* wsr = ws ? ws + s2d_x_floats(g) + s2d_w_floats(g) : nullptr;
+        if (prep <= 0) {
+            hipLaunchKernelGGL(w5x5_s2d_kernel, dim3(ew_grid((int64_t)g->Cout * 36 * g->Cin, 256)), dim3(256), 0, s2, w, w2, g->Cout, g->Cin, 1);
+            TG_CHECK_LAUNCH("w5x5_s2d_kernel");
+        }
         {
             AlgScale sc(25.0 / 36.0);
-            rc = conv_dgrad_impl(&g2, dy, w2, nullptr, dx2, 0, nullptr, 0, 0.f, wsr,
-                                 ws_bytes - (s2d_x_floats(g) + s2d_w_floats(g)) * sizeof(float), stream);
+            rc = conv_dgrad_impl(&g2, dy, w2, prep ? wprep + s2d_w_floats(g) : nullptr, prep, nullptr, dx2, 0, nullptr, 0, 0.f, wsr,
+                                 ws ? ws_bytes - (s2d_x_floats(g) + s2d_w_floats(g)) * sizeof(float) : 0, stream);
         }
-        if (rc) return rc;
+        if (rc || prep < 0) return rc;
         hipLaunchKernelGGL(d2s_kernel, dim3(ew_grid((int64_t)g->B * g->H * g->W * (g->Cin / 4), 256)), dim3(256), 0, s2, dx2, in_mask, dx,
                            g->B, g->H, g->W, g->Cin, accumulate);
         TG_CHECK_LAUNCH("d2s_kernel");
         return TG_OK;
     }
+    TG_REQUIRE(!(s2d_ok(g) && gate == nullptr && prep > 0), "tg_conv_dgrad: workspace too small for the prepared 5x5 stride-2 path");
     const int taps = g->k * g->k;
-    const size_t wt_floats = dgrad_wt_floats(g);
-    TG_REQUIRE(ws_bytes >= wt_floats * sizeof(float), "tg_conv_dgrad: workspace too small (%zu < %zu)", ws_bytes,
+    // head of the workspace = transposed / transformed weights unless the caller prepared them
+    const size_t wt_floats = prep ? 0 : dgrad_wt_floats(g);
+    TG_REQUIRE(prep < 0 || ws_bytes >= wt_floats * sizeof(float), "tg_conv_dgrad: workspace too small (%zu < %zu)", ws_bytes,
                wt_floats * sizeof(float));
     hipStream_t s = (hipStream_t)stream;
-    float* ws2 = ws + wt_floats;
-    const size_t ws2_floats = ws_bytes / sizeof(float) - wt_floats;
-    if (conv_wino_floats(g)) {
+    float* wt = prep ? wprep : ws;
+    float* ws2 = ws ? ws + wt_floats : nullptr;
+    const size_t ws2_floats = ws ? ws_bytes / sizeof(float) - wt_floats : 0;
+    if (wino_dgrad_geom_ok(g)) {
         // stride-1 3x3: the Winograd kernel reads W[co][tap][ci] through strides (n = ci, k = co); no transposed copy
         IGemmParams p = {};
         p.src = dy; p.rowscale = in_mask; p.dst = dx; p.ws = ws2;
@@ -1251,12 +1326,17 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, con
         p.gate = gate; p.gate_act = gate_act; p.gate_slope = gate_slope;
         p.bf16 = g->precision == TG_PREC_BF16;
         p.w_raw = w; p.w_sn = 1; p.w_sk = (long)taps * g->Cin; p.w_stap = g->Cin;
-        p.wino_u = ws;
-        if (wino_ok(p)) return launch_wino(p, ws2_floats, s);
+        p.wino_u = wt;
+        p.wino_ready = prep;
+        TG_REQUIRE(wino_ok(p), "tg_conv_dgrad: internal: Winograd geometry predicate mismatch");
+        return launch_wino(p, ws2_floats, s);
     }
-    hipLaunchKernelGGL(transpose_w_kernel, dim3(ew_grid((int64_t)g->Cout * taps * g->Cin, 256)), dim3(256), 0, s, w, ws,
-                       g->Cout, taps, g->Cin);
-    TG_CHECK_LAUNCH("transpose_w_kernel");
+    if (prep <= 0) {
+        hipLaunchKernelGGL(transpose_w_kernel, dim3(ew_grid((int64_t)g->Cout * taps * g->Cin, 256)), dim3(256), 0, s, w, wt,
+                           g->Cout, taps, g->Cin);
+        TG_CHECK_LAUNCH("transpose_w_kernel");
+    }
+    if (prep < 0) return TG_OK;
 
     const int st = g->stride;
     IGemmParams cls[4];
@@ -1265,7 +1345,7 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, con
     for (int py = 0; py < st; ++py) {
         for (int px = 0; px < st; ++px) {
             IGemmParams p = {};
-            p.src = dy; p.amask = nullptr; p.wmat = ws; p.bias = nullptr; p.rowscale = in_mask; p.dst = dx; p.ws = ws2;
+            p.src = dy; p.amask = nullptr; p.wmat = wt; p.bias = nullptr; p.rowscale = in_mask; p.dst = dx; p.ws = ws2;
             p.B = g->B; p.IH = g->Ho; p.IW = g->Wo; p.C = g->Cout;
             p.OH = (g->H - py + st - 1) / st; p.OW = (g->W - px + st - 1) / st;
             if (p.OH <= 0 || p.OW <= 0) continue;

@@ -30,6 +30,7 @@ struct IGemmParams {
     const float* w_raw;
     long w_sn, w_sk, w_stap;
     float* wino_u;
+    int wino_ready;         // wino_u already holds the transformed weights (prepared by tg_conv_wprep): skip the transform
 };
 __device__ __forceinline__ float gate_factor(const IGemmParams& p, size_t idx) {
     const float gv = p.gate[idx];

@@ -107,9 +107,11 @@ def broadcast_state(modules=(), optimizers=(), src=0, group=None):
     rank, world = rank_world(group)
     if world == 1:
         return
+    from . import ops as O
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
             dist.broadcast(t.data, src=src, group=group)
+        O.weights_updated(list(m.parameters()))       # written behind torch's version counter: prepared conv weights are stale
     for opt in optimizers:
         # state may be empty on some ranks only if it is empty on all (a fresh optimiser): exchange the structure first
         meta = [opt.state_dict()] if rank == src else [None]

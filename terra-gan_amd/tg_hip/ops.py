@@ -91,6 +91,48 @@ def conv_geom(x, cout, k, stride, pad):
     return L.TgConv(B, H, W, Cin, Ho, Wo, cout, k, stride, pad, _precision)
 
 
+# ---- prepared weights (tg_conv_wprep): computed when a weight tensor is first used and again only after it changed --------
+WPREP_FWD, WPREP_DGRAD = 0, 1
+WPREP_CACHE = True            # False: every conv call prepares its weights in the workspace (the round-1 behaviour)
+_wprep = {}                   # (weight ptr, mode, geometry) -> [weakref(weight), version stamp, prepared buffer or None]
+_wstamp = {}                  # weight ptr -> number of out-of-band updates (kernels writing through raw pointers)
+
+
+def weights_updated(params):
+    """To be called by whoever rewrites parameters through raw pointers (hip_adam_step): torch's version counter does not
+    see such writes, so the prepared-weight cache keeps its own stamp per storage."""
+    for p in params:
+        if p.dim() == 4:
+            ptr = p.data_ptr()
+            _wstamp[ptr] = _wstamp.get(ptr, 0) + 1
+
+
+def _prepared(w, wv, g, mode):
+    """Prepared form of weight `w` for (g, mode), or None when that path reads the raw weights."""
+    if not WPREP_CACHE:
+        return None
+    import weakref
+    ptr = wv.data_ptr()
+    key = (ptr, mode, g.H, g.W, g.Cin, g.Cout, g.k, g.stride, g.pad, g.precision)
+    stamp = (w._version, _wstamp.get(ptr, 0))
+    ent = _wprep.get(key)
+    if ent is not None and ent[0]() is w and ent[1] == stamp:
+        return ent[2]
+    lib = _lib()
+    if ent is None or ent[0]() is not w:            # first use (or the address was recycled for another tensor)
+        nb = lib.tg_conv_wprep_bytes(C.byref(g), mode)
+        buf = torch.empty((nb + 3) // 4, dtype=torch.float32, device=wv.device) if nb else None
+        if len(_wprep) > 512:
+            for k_ in [k_ for k_, e in _wprep.items() if e[0]() is None]:
+                del _wprep[k_]
+        ent = [weakref.ref(w), None, buf]
+        _wprep[key] = ent
+    if ent[2] is not None:
+        L.check(lib.tg_conv_wprep(C.byref(g), mode, _p(wv), _p(ent[2]), _stream()), "tg_conv_wprep")
+    ent[1] = stamp
+    return ent[2]
+
+
 def conv_fwd(x, w, bias, k, stride, pad, in_mask=None, ratio=None, act=ACT_NONE, slope=0.0):
     _chk(x, "x"); _chk(bias, "bias"); _chk(in_mask, "in_mask"); _chk(ratio, "ratio")
     wv = weight_view(w)
@@ -101,8 +143,8 @@ def conv_fwd(x, w, bias, k, stride, pad, in_mask=None, ratio=None, act=ACT_NONE,
     lib = _lib()
     nb = lib.tg_conv_fwd_ws_bytes(C.byref(g))
     ws = workspace(nb)
-    L.check(lib.tg_conv_fwd(C.byref(g), _p(x), _p(in_mask), _p(wv), _p(bias), _p(ratio), act, slope, _p(y), _p(ws),
-                            ws.numel() * 4, _stream()), "tg_conv_fwd")
+    L.check(lib.tg_conv_fwd_p(C.byref(g), _p(x), _p(in_mask), _p(wv), _p(_prepared(w, wv, g, WPREP_FWD)), _p(bias), _p(ratio),
+                              act, slope, _p(y), _p(ws), ws.numel() * 4, _stream()), "tg_conv_fwd")
     return y
 
 
@@ -119,11 +161,9 @@ def conv_dgrad(dy, w, x_shape, k, stride, pad, in_mask=None, out=None, gate=None
     ws = workspace(lib.tg_conv_dgrad_ws_bytes(C.byref(g)))
     if gate is not None:
         assert out is None and tuple(gate.shape) == tuple(x_shape)
-        L.check(lib.tg_conv_dgrad_gated(C.byref(g), _p(dy), _p(wv), _p(in_mask), _p(gate), gate_act, gate_slope, _p(dx), _p(ws),
-                                        ws.numel() * 4, _stream()), "tg_conv_dgrad_gated")
-        return dx
-    L.check(lib.tg_conv_dgrad(C.byref(g), _p(dy), _p(wv), _p(in_mask), _p(dx), acc, _p(ws), ws.numel() * 4, _stream()),
-            "tg_conv_dgrad")
+    L.check(lib.tg_conv_dgrad_p(C.byref(g), _p(dy), _p(wv), _p(_prepared(w, wv, g, WPREP_DGRAD)), _p(in_mask), _p(gate),
+                                gate_act if gate is not None else ACT_NONE, gate_slope, _p(dx), acc, _p(ws), ws.numel() * 4,
+                                _stream()), "tg_conv_dgrad")
     return dx
 
 
@@ -373,6 +413,7 @@ def adam_(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
             raise L.TgError(f"adam_: {nm} layout {tuple(t.shape)}/{t.stride()} differs from the parameter's "
                             f"{tuple(p.shape)}/{p.stride()}")
     L.check(_lib().tg_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _stream()), "tg_adam")
+    weights_updated([p])
 
 
 ADAM_CHUNK = 1 << 14
@@ -405,6 +446,7 @@ def adam_multi_(params, grads, ms, vs, lr, beta1, beta2, eps, step, grad_scale=1
     segs, work, nwork = ent
     L.check(_lib().tg_adam_multi(C.c_void_p(segs.data_ptr()), C.c_void_p(work.data_ptr()), nwork, ADAM_CHUNK, lr, beta1, beta2,
                                  eps, step, grad_scale, _stream()), "tg_adam_multi")
+    weights_updated(params)          # prepared conv weights of these tensors are stale now
 
 
 def axpby_(x, a, b, y):

@@ -90,6 +90,11 @@ int tg_conv_dgrad_p(const TgConv* g, const float* dy, const float* w, const floa
                     const float* x_act, int act, float slope, float* dx, int accumulate, float* ws,
                     size_t ws_bytes, tg_stream_t stream);
 
+/* Leave `cus` of the 256 CUs free in the launches that otherwise occupy every CU with one long-running workgroup (the
+ * Winograd kernels): data-parallel runs set this so that RCCL's kernels on the communication stream can be scheduled
+ * while a convolution is running (0 = default, single-GPU). */
+int tg_set_cu_reserve(int cus);
+
 /* dw[Cout][k][k][Cin] = sum_pixels dy (x) (x (.) in_mask);  db[Cout] = sum_pixels dy (db may be NULL).
  * Deterministic: split-K partial slabs in ws, reduced in a fixed order. */
 size_t tg_conv_wgrad_ws_bytes(const TgConv* g);

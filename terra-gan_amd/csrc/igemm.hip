@@ -124,6 +124,41 @@ extern "C" int tg_prof_summary(int kind, double* total_ms, int64_t* launches, do
 // ------------------------------------------------------------------------------------------------
 #include "igemm_params.h"
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: opt in once per (kernel, device) --
+// a process that drives a second GPU would otherwise launch the >64 KB-LDS kernels there without it.  Thread-safe.
+struct LdsOptIn {
+    std::mutex mu;
+    bool done[64] = {};
+};
+static int lds_opt_in(LdsOptIn& st, const void* kern, size_t lds, const char* who) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(st.mu);
+    if (dev >= 0 && dev < 64 && st.done[dev]) return TG_OK;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        tg_set_error("%s: hipFuncSetAttribute(%zu) failed: %s", who, lds, hipGetErrorString(e));
+        return TG_ERR_LAUNCH;
+    }
+    if (dev >= 0 && dev < 64) st.done[dev] = true;
+    return TG_OK;
+}
+
+// CUs left free by the one-workgroup-per-CU Winograd kernels (tg_set_cu_reserve).  Those workgroups own their CU for the
+// whole launch (141 KB LDS, 512 threads): a concurrent stream's small kernels -- RCCL's reduction kernels in a
+// data-parallel run, whose gradient all-reduce is meant to run underneath the next kernels -- would otherwise queue behind
+// a full launch.  248 of 256 workgroups dealt round-robin over the 8 XCDs leave one CU per XCD free.
+static int g_cu_reserve = 0;
+static int wino_cus() {
+    const int c = 256 - g_cu_reserve;
+    return c < 8 ? 8 : c;
+}
+extern "C" int tg_set_cu_reserve(int cus) {
+    TG_REQUIRE(cus >= 0 && cus <= 128, "tg_set_cu_reserve: %d out of range [0,128]", cus);
+    g_cu_reserve = cus;
+    return TG_OK;
+}
+
 // Split-K factor with wave quantisation in mind: `slots` workgroups are resident at once (CUs x occupancy); a grid
 // of 1.3 x slots long-running workgroups takes as long as 2 x slots.  Pick the smallest split count whose grid
 // fills at least one round and wastes <= 8 % of its last round, else the most efficient one.
@@ -154,21 +189,6 @@ __device__ __forceinline__ int xcd_remap(int id, int total) {
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
 }
 
-// Epilogue helper.  The MFMA C layout gives a lane ONE column and 16 rows of a 32x32 tile, i.e. 16 single-dword
-// stores per tile and lane; such an epilogue is store-ISSUE bound (it cost the patch kernel ~6 K-steps per workgroup).
-// The wave bounces the tile through its own 32x36-float LDS scratch and comes back with 4 consecutive columns of one
-// row per lane: emit(row_in_tile, col_in_tile, f32x4) is called 4 times per lane -> 4 x 16-byte stores instead of
-// 16 x 4-byte ones.  A wave reads back only what it wrote itself (LDS ops of one wave complete in order): no barrier.
-template <class F>
-__device__ __forceinline__ void tile_rows4(float* scratch, const f32x16& acc, int lane, F&& emit) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[r];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int rr = (lane >> 3) + 8 * t;
-        emit(rr, 4 * (lane & 7), *reinterpret_cast<const f32x4*>(scratch + rr * 36 + 4 * (lane & 7)));
-    }
-}
 __device__ __forceinline__ f32x4 epilogue4(const IGemmParams& p, f32x4 o, size_t pix, int nb) {
     const float rs = p.rowscale ? p.rowscale[pix] : 1.f;
     if (p.bias) o += *reinterpret_cast<const f32x4*>(p.bias + nb);
@@ -525,17 +545,9 @@ template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR, bool BF16 = fal
 static int launch_igemm_cfg(const IGemmParams& p, hipStream_t s) {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
     constexpr size_t lds = (size_t)2 * (BM + BN) * (BF16 ? 40 * 2 : 36 * sizeof(float));
-    static bool attr_done = false;
+    static LdsOptIn opt;
     auto kern = igemm_kernel<WAVES_M, WAVES_N, WM, WN, SCALAR, BF16>;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            tg_set_error("igemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return TG_ERR_LAUNCH;
-        }
-        attr_done = true;
-    }
+    if (int rc = lds_opt_in(opt, reinterpret_cast<const void*>(kern), lds, "igemm")) return rc;
     dim3 grid(cdiv(p.M, BM), cdiv(p.N, BN), p.splits);
     {
         // algorithmic bytes: source pixels touched once + row scale/mask + weights + output
@@ -857,16 +869,11 @@ static int launch_pgemm_cfg(const IGemmParams& p, const PatchGeom& q, double flo
     int ppix = 0;
     for (int i = 0; i < q.ncls; ++i) ppix = q.c[i].PH * q.c[i].PW > ppix ? q.c[i].PH * q.c[i].PW : ppix;
     const size_t lds = ((size_t)2 * BN + (size_t)ppix) * (BF16 ? 40 * 2 : 36 * sizeof(float));
-    static size_t attr_lds = 0;
+    static LdsOptIn opt;
     auto kern = pgemm_kernel<TH_, TW_, WAVES_M, WAVES_N, WM, WN, MAXPL, BF16>;
-    if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            tg_set_error("pgemm: hipFuncSetAttribute(%zu) failed: %s", lds, hipGetErrorString(e));
-            return TG_ERR_LAUNCH;
-        }
-        attr_lds = lds;
-    }
+    constexpr size_t LDS_MAX = 96 * 1024;       // the opt-in is a ceiling (largest patch: 19 x 19 pixels), not an allocation
+    if (lds > LDS_MAX) { tg_set_error("pgemm: %zu bytes of LDS requested", lds); return TG_ERR_ARG; }
+    if (int rc = lds_opt_in(opt, reinterpret_cast<const void*>(kern), LDS_MAX, "pgemm")) return rc;
     dim3 grid(q.total_work, 1, p.splits);
     {
         ProfScope ps(s, BF16 ? 3 : 0, flops, bytes, Mtot, p.N, p.Ktot, p.C, p.splits, (BF16 ? 3000 : 1000) + BN);
@@ -1843,17 +1850,9 @@ template <int WAVES_M, int WAVES_N, int WM, int WN, bool SA, bool SB>
 static int launch_wgrad_cfg(const WgradParams& p, hipStream_t s) {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
     constexpr size_t lds = (size_t)2 * 32 * (BM + BN) * sizeof(float);
-    static bool attr_done = false;
+    static LdsOptIn opt;
     auto kern = wgrad_kernel<WAVES_M, WAVES_N, WM, WN, SA, SB>;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            tg_set_error("wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return TG_ERR_LAUNCH;
-        }
-        attr_done = true;
-    }
+    if (int rc = lds_opt_in(opt, reinterpret_cast<const void*>(kern), lds, "wgrad")) return rc;
     WgradParams pp = p;
     pp.rowseg = (p.Wo % 32 == 0 && !SB && !getenv("TG_NO_ROWSEG")) ? 1 : 0;
     pp.nx = cdiv(p.Ktot, BN);

@@ -101,6 +101,144 @@ __global__ __launch_bounds__(256) void c1conv_kernel(const IGemmParams p, const 
     }
 }
 
+
+// ---- 1 source channel -> N channels on the fp32 MFMA (K = taps) ---------------------------------------------------------
+// The lane-per-channel kernel above issues ONE broadcast ds_read_b32 per FMA: for enc1 (7x7: 49 taps) that is 12.8 M LDS
+// wave-instructions, and the kernel runs at 0.93 TB/s (12 % of HBM) although it only has to write 67 MB.  As a GEMM the layer
+// is M = pixels, N = 64, K = 49: thin, but v_mfma_f32_32x32x2_f32 needs just 25 K-steps, i.e. the matrix pipe is busy for
+// ~11 us chip-wide -- the same as the output stream at the HBM rate.  A wave owns 4 rows x 16 pixels x 64 channels of the
+// 16x16 tile (2 x 2 accumulator tiles); its A operand is an im2col view of the 1-channel patch in LDS (lane = pixel, lane
+// half = one of the step's two taps: one ds_read_b32 per MFMA pair), its B operand the zero-padded [K][64] weight image in
+// LDS.  The epilogue bounces each 32x32 tile through LDS (tile_rows4) for 16-byte NHWC stores.  Exact fp32 arithmetic
+// (the MFMA is an fma chain over k).
+template <int TH_, int TW_>
+__global__ __launch_bounds__(256) void c1mfma_kernel(const IGemmParams p, const C1Geom q) {
+    constexpr int NT = TH_ * TW_, KS = (NT + 1) / 2;
+    constexpr int WLP = 68;                      // row pitch of the weight image: the transposing stores spread over the banks
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* wl = sm;                              // [2*KS][WLP]  (row NT is zero when NT is odd)
+    float* scratch = sm + 2 * KS * WLP;          // [4 waves][32*36]
+    float* patch = scratch + 4 * 32 * 36;        // [PH*PW]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int tile = blockIdx.x;
+    const int txi = tile % q.tiles_x;
+    tile /= q.tiles_x;
+    const int tyi = tile % q.tiles_y, b = tile / q.tiles_y;
+    const int oy0 = tyi * C1_T, ox0 = txi * C1_T;
+    const int n0 = blockIdx.y * 64;
+    {
+        // Staging with every global load of the workgroup in flight at once: a rolled loop (runtime trip count) costs one
+        // L2 / HBM round trip per iteration -- ~15 us of the first version's 54 us on enc1, where all workgroups of a CU
+        // start together and nothing else covers it.
+        constexpr int PMAX = (15 * 2 + TH_) * (15 * 2 + TW_);      // largest patch (stride 2)
+        constexpr int PIT = (PMAX + 255) / 256, WIT = (NT * 64 + 255) / 256;
+        const int py0 = oy0 * p.ss + q.sy_min, px0 = ox0 * p.ss + q.sx_min, pn = q.PH * q.PW;
+        float pv[PIT], pm[PIT], wv[WIT];
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            const int i = threadIdx.x + 256 * it;
+            const int py = i / q.PW, px = i - py * q.PW;
+            const int iy = py0 + py, ix = px0 + px;
+            const bool in = i < pn && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            const size_t pix = in ? ((size_t)b * p.IH + iy) * p.IW + ix : 0;
+            pv[it] = p.src[pix];
+            pm[it] = !in ? 0.f : (p.amask ? p.amask[pix] : 1.f);
+        }
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {       // k fastest: a channel's taps are contiguous in memory
+            const int i = threadIdx.x + 256 * it;
+            const int c = i / NT, k = i - c * NT;
+            wv[it] = i < NT * 64 ? p.wmat[(size_t)(n0 + c) * p.Kfull + weight_tap(p, k / TW_, k % TW_)] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < PIT; ++it) {
+            const int i = threadIdx.x + 256 * it;
+            if (i < pn) patch[i] = pm[it] != 0.f ? pv[it] * pm[it] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = threadIdx.x + 256 * it;
+            const int c = i / NT, k = i - c * NT;
+            if (i < NT * 64) wl[k * WLP + c] = wv[it];
+        }
+        if constexpr (NT & 1)
+            if (threadIdx.x < 64) wl[NT * WLP + threadIdx.x] = 0.f;      // the padded K row
+    }
+    __syncthreads();
+    const int h = lane >> 5, pi = lane & 31;
+    const int oyy = p.sy0 - q.sy_min, oxx = p.sx0 - q.sx_min;
+    // patch address of this lane's pixel in M tile m (rows 2m, 2m+1 of the wave's 4 rows)
+    int abase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+        abase[m] = ((wave * 4 + 2 * m + (pi >> 4)) * p.ss + oyy) * q.PW + (pi & 15) * p.ss + oxx;
+    const int ty_step = p.tstep * q.PW, tx_step = p.tstep;
+    float* sc = scratch + wave * (32 * 36);
+    // epilogue operands are requested BEFORE the MFMAs they follow: a load issued between two output stores cannot be
+    // hoisted by the compiler (the stores may alias it), and 16 load -> wait -> store round trips per wave cost more
+    // than the whole K loop
+    const int ecc = 4 * (lane & 7), err = lane >> 3;
+    f32x4 bias4[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+        bias4[nt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + 32 * nt + ecc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // M tile by M tile: the (asynchronous) output stores of tile 0 drain underneath the MFMAs of tile 1, and the four
+    // workgroups of a CU, which start together, stop marching through their load / MFMA / store phases in lockstep
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        size_t opix[4];
+        float rs[4];
+        bool ok[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {            // tile_rows4 hands this lane rows err + 8t of the 32-pixel tile
+            const int rr = err + 8 * t;
+            const int oy = oy0 + wave * 4 + 2 * m + (rr >> 4), ox = ox0 + (rr & 15);
+            ok[t] = oy < p.OH && ox < p.OW;
+            opix[t] = ok[t] ? out_pixel(p, b, oy, ox) : 0;
+            rs[t] = p.rowscale ? p.rowscale[opix[t]] : 1.f;
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            // taps k0 = 2s (lane half 0) and k1 = 2s+1 (lane half 1; the zero weight row when k1 == NT, any valid address)
+            const int k0 = 2 * s, k1 = 2 * s + 1 < NT ? 2 * s + 1 : 2 * s;
+            const int off0 = (k0 / TW_) * ty_step + (k0 % TW_) * tx_step, off1 = (k1 / TW_) * ty_step + (k1 % TW_) * tx_step;
+            float a = patch[abase[m] + (h ? off1 : off0)];
+            if (2 * s + 1 >= NT && h) a = 0.f;                      // padded K row: 0 * w(=0), never 0 * inf
+            const float b0 = wl[(2 * s + h) * WLP + pi], b1 = wl[(2 * s + h) * WLP + 32 + pi];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            // (tile_rows4 inlined: the row index t must be a compile-time constant to address opix / rs / ok)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[nt][r];
+            const int n = n0 + 32 * nt + ecc;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(sc + (err + 8 * t) * 36 + ecc);
+                if (!ok[t]) continue;
+                v = (v + bias4[nt]) * rs[t];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.slope);
+                float* d = p.dst + opix[t] * p.N + n;
+                if (p.gate) {
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(p.gate + opix[t] * p.N + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= gv[e] > 0.f ? 1.f : (p.gate_act == TG_ACT_LEAKY ? p.gate_slope : 0.f);
+                }
+                if (p.accumulate) v += *reinterpret_cast<const f32x4*>(d);
+                *reinterpret_cast<f32x4*>(d) = v;
+            }
+        }
+    }
+}
+
 // ---- 64 channels -> 1 channel: lane = (pixel of a 4-pixel row segment, channel quad) --------------------------
 // Each lane loads float4 (4 channels), so one wave instruction fetches the full 256-B rows of 4 neighbouring
 // pixels; the row base is wave-uniform (scalar ALU), the tap loops are unrolled and predicated, and the channel
@@ -187,6 +325,17 @@ int smallconv_fwd_launch(const IGemmParams& p, hipStream_t s) {
         q.PH = (C1_T - 1) * p.ss + (p.TH - 1) + 1;
         q.PW = (C1_T - 1) * p.ss + (p.TW - 1) + 1;
         dim3 grid(q.tiles_x * q.tiles_y * p.B, p.N / 64);
+        static const bool no_mfma = getenv("TG_NO_C1MFMA") != nullptr;
+        const bool al16 = ((reinterpret_cast<uintptr_t>(p.dst) | reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.gate)) & 15) == 0;
+        if (!no_mfma && al16 && p.TH == p.TW && (p.TH == 7 || p.TH == 4 || p.TH == 3)) {
+            const int ks = (p.TH * p.TW + 1) / 2;
+            const size_t lds = ((size_t)2 * ks * 68 + 4 * 32 * 36 + (size_t)q.PH * q.PW) * sizeof(float);
+            if (p.TH == 7) hipLaunchKernelGGL((c1mfma_kernel<7, 7>), grid, dim3(256), lds, s, p, q);
+            else if (p.TH == 4) hipLaunchKernelGGL((c1mfma_kernel<4, 4>), grid, dim3(256), lds, s, p, q);
+            else hipLaunchKernelGGL((c1mfma_kernel<3, 3>), grid, dim3(256), lds, s, p, q);
+            TG_CHECK_LAUNCH("c1mfma_kernel");
+            return TG_OK;
+        }
         const size_t lds = ((size_t)q.PH * q.PW + (size_t)p.TH * p.TW * 64) * sizeof(float);
         if (p.TH == 7 && p.TW == 7) hipLaunchKernelGGL((c1conv_kernel<7, 7>), grid, dim3(256), lds, s, p, q);
         else if (p.TH == 4 && p.TW == 4) hipLaunchKernelGGL((c1conv_kernel<4, 4>), grid, dim3(256), lds, s, p, q);

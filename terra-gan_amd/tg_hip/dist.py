@@ -32,9 +32,19 @@ class Bucket:
 
 
 class GradSync:
-    def __init__(self, world_size=None, bucket_mb=25.0, group=None):
+    def __init__(self, world_size=None, bucket_mb=25.0, group=None, cu_reserve=None):
+        """cu_reserve: CUs the one-workgroup-per-CU Winograd launches leave free so that RCCL's kernels can run underneath
+        them (tg_set_cu_reserve).  Default: $TG_CU_RESERVE, else 8 (one per XCD) when world_size > 1.  UNMEASURED on a
+        multi-GPU node (the build box has one GPU): the value is a tunable, not a tuned constant."""
         self.group = group
         self.world_size = world_size if world_size is not None else dist.get_world_size(group)
+        import os
+        if cu_reserve is None:
+            cu_reserve = int(os.environ.get("TG_CU_RESERVE", "8" if self.world_size > 1 else "0"))
+        self.cu_reserve = cu_reserve
+        if torch.cuda.is_available():
+            from . import lib as L
+            L.check(L.load().tg_set_cu_reserve(int(cu_reserve)), "tg_set_cu_reserve")
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self._plans = {}
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     "tg_conv_dgrad_ws_bytes": (SZ, [CP]),
     "tg_conv_dgrad": (I, [CP, P, P, P, P, I, P, SZ, P]),
     "tg_conv_dgrad_gated": (I, [CP, P, P, P, P, I, F, P, P, SZ, P]),
+    "tg_set_cu_reserve": (I, [I]),
     "tg_conv_wprep_bytes": (SZ, [CP, I]),
     "tg_conv_wprep": (I, [CP, I, P, P, P]),
     "tg_conv_fwd_p": (I, [CP, P, P, P, P, P, P, I, F, P, P, SZ, P]),

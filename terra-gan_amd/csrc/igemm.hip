@@ -955,6 +955,7 @@ static bool try_pgemm(IGemmParams* ps, int ncls, size_t ws_floats_avail, hipStre
 }
 
 #include "wino.inc"
+#include "wino16.inc"
 
 static int pick_bn(int N) { return N >= 128 && N % 128 == 0 ? 128 : (N > 32 ? 64 : 32); }
 
@@ -982,6 +983,7 @@ static int launch_igemm(IGemmParams& p, hipStream_t s, size_t ws_floats_avail = 
         return smallconv_fwd_launch(p, s);
     }
     if (wino_ok(p)) return launch_wino(p, ws_floats_avail, s);
+    if (wino16_ok(p)) return launch_wino16(p, ws_floats_avail, s);
     {
         int rc = TG_OK;
         if (try_pgemm(&p, 1, ws_floats_avail, s, &rc)) return rc;
@@ -1090,7 +1092,7 @@ __global__ __launch_bounds__(256) void w5x5_s2d_kernel(const float* __restrict__
 }
 static bool s2d_ok(const TgConv* g) {
     static const bool off = getenv("TG_NO_WINO") != nullptr || getenv("TG_NO_S2D") != nullptr;
-    if (off || g->precision == TG_PREC_BF16) return false;
+    if (off || (g->precision == TG_PREC_BF16 && getenv("TG_NO_WINO16"))) return false;
     return g->k == 5 && g->stride == 2 && g->pad == 2 && (g->H % 2) == 0 && (g->W % 2) == 0 && (g->Cin % 16) == 0 &&
            (g->Cout % 64) == 0 && g->Ho >= 32 && g->Wo >= 32 && g->Ho == g->H / 2 && g->Wo == g->W / 2;   // smaller: not worth 3 extra passes
 }
@@ -1122,15 +1124,20 @@ extern "C" size_t tg_conv_fwd_ws_bytes(const TgConv* g) {
 // depends on the weights only, so the caller may have it computed ONCE per optimiser step (once ever for the frozen VGG
 // trunk) by tg_conv_wprep and hand it to tg_conv_fwd_p / tg_conv_dgrad_p.  `prep`: 0 = none given (prepare per call in
 // the workspace, the tg_conv_fwd / tg_conv_dgrad behaviour), 1 = `wprep` is ready, -1 = fill `wprep` and return.
+// (bf16 mode: wino16_kernel walks K in 16-channel steps)
+static int wino_kc(const TgConv* g) {
+    static const bool off16 = getenv("TG_NO_WINO16") != nullptr;
+    return g->precision == TG_PREC_BF16 ? (off16 ? 0 : 16) : 8;
+}
 static bool wino_fwd_geom_ok(const TgConv* g) {
     static const bool off = getenv("TG_NO_WINO") != nullptr;
-    return !off && g->precision != TG_PREC_BF16 && g->k == 3 && g->stride == 1 && (g->Cin % 8) == 0 && (g->Cout % WINO_BN) == 0 &&
-           g->Ho >= 16 && g->Wo >= 16;
+    const int kc = wino_kc(g);
+    return !off && kc && g->k == 3 && g->stride == 1 && (g->Cin % kc) == 0 && (g->Cout % WINO_BN) == 0 && g->Ho >= 16 && g->Wo >= 16;
 }
 static bool wino_dgrad_geom_ok(const TgConv* g) {
     static const bool off = getenv("TG_NO_WINO") != nullptr;
-    return !off && g->precision != TG_PREC_BF16 && g->k == 3 && g->stride == 1 && (g->Cout % 8) == 0 && (g->Cin % WINO_BN) == 0 &&
-           g->H >= 16 && g->W >= 16;
+    const int kc = wino_kc(g);
+    return !off && kc && g->k == 3 && g->stride == 1 && (g->Cout % kc) == 0 && (g->Cin % WINO_BN) == 0 && g->H >= 16 && g->W >= 16;
 }
 static size_t dgrad_wt_floats(const TgConv* g);
 extern "C" size_t tg_conv_wprep_bytes(const TgConv* g, int mode) {
@@ -1193,7 +1200,7 @@ static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, 
         p.w_raw = w; p.w_sn = (long)p.Kfull; p.w_sk = 1; p.w_stap = g->Cin;
         p.wino_u = prep ? wprep : ws;
         p.wino_ready = prep;
-        TG_REQUIRE(wino_ok(p), "tg_conv_fwd: internal: Winograd geometry predicate mismatch");
+        TG_REQUIRE(p.bf16 ? wino16_ok(p) : wino_ok(p), "tg_conv_fwd: internal: Winograd geometry predicate mismatch");
         if (!prep) {
             p.ws = ws + uf;
             ws_floats -= uf;
@@ -1335,8 +1342,8 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, flo
         p.w_raw = w; p.w_sn = 1; p.w_sk = (long)taps * g->Cin; p.w_stap = g->Cin;
         p.wino_u = wt;
         p.wino_ready = prep;
-        TG_REQUIRE(wino_ok(p), "tg_conv_dgrad: internal: Winograd geometry predicate mismatch");
-        return launch_wino(p, ws2_floats, s);
+        TG_REQUIRE(p.bf16 ? wino16_ok(p) : wino_ok(p), "tg_conv_dgrad: internal: Winograd geometry predicate mismatch");
+        return p.bf16 ? launch_wino16(p, ws2_floats, s) : launch_wino(p, ws2_floats, s);
     }
     if (prep <= 0) {
         hipLaunchKernelGGL(transpose_w_kernel, dim3(ew_grid((int64_t)g->Cout * taps * g->Cin, 256)), dim3(256), 0, s, w, wt,

@@ -163,3 +163,78 @@ def test_config3_bf16_train_step_fullsize(dev):
         assert torch.equal(a, b_)
     for (g16, d16), (g32, d32) in zip(runs["bf16_a"][0], runs["f32"][0]):
         assert g16 == g16 and abs(g16 - g32) <= 2e-2 * abs(g32) and abs(d16 - d32) <= 2e-2 * abs(d32), (runs["bf16_a"][0], runs["f32"][0])
+
+
+# ---- bf16-operand Winograd (wino16_kernel): stride-1 3x3 with Cin % 16 == 0, Cout % 64 == 0, >= 16x16 outputs, and the
+# 5x5 stride-2 layers through space-to-depth.  Reference: PyTorch-CPU fp64 of the same convolution.  Transforms are fp32
+# and only the transformed operands are rounded to bf16, so the error budget is that of any bf16 conv: ~2^-9 per product.
+W16_CASES = [   # B, H, W, Cin, Cout, k, stride, pad
+    (2, 32, 32, 64, 64, 3, 1, 1),
+    (1, 40, 24, 16, 64, 3, 1, 1),        # ragged tiles, a single 16-channel K step
+    (3, 17, 19, 48, 128, 3, 1, 1),       # odd sizes
+    (2, 16, 16, 2048, 128, 3, 1, 1),     # long K -> split-K slabs
+    (1, 64, 48, 192, 64, 3, 1, 1),
+    (2, 20, 20, 16, 64, 3, 1, 0),        # pad 0
+    (2, 64, 64, 32, 64, 5, 2, 2),        # 5x5 stride 2 -> 3x3 over the space-to-depth input (enc2 / enc3 shape family)
+]
+
+
+@pytest.mark.parametrize("case", W16_CASES)
+def test_wino16_fwd_dgrad(dev, case):
+    import torch.nn.functional as F
+    from tg_hip import ops as O
+    B, H, W, Cin, Cout, k, s_, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (k * Cin ** 0.5)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    mask = (torch.rand(B, H, W, generator=g) > 0.3).float()
+    wd = w.contiguous(memory_format=torch.channels_last).to(dev)
+    O.set_precision("bf16")
+    _, ratio_d = O.mask_update(mask.to(dev), k, s_, pad)
+    ratio = ratio_d.cpu()
+    # forward: masked input, bias, ratio, ReLU
+    y = O.conv_fwd(x.to(dev), wd, bias.to(dev), k, s_, pad, in_mask=mask.to(dev), ratio=ratio_d, act=O.ACT_RELU)
+    ref = F.conv2d((x * mask[..., None]).permute(0, 3, 1, 2).double(), w.double(), bias.double(), s_, pad).permute(0, 2, 3, 1)
+    ref = (ref * ratio[..., None].double()).clamp_min(0)
+    err = (y.cpu().double() - ref)
+    assert float(err.norm() / ref.norm()) < 6e-3, float(err.norm() / ref.norm())
+    assert float(err.abs().max()) < 3e-2 * float(ref.abs().max()), (float(err.abs().max()), float(ref.abs().max()))
+    # plain forward without any epilogue operand
+    y0 = O.conv_fwd(x.to(dev), wd, None, k, s_, pad)
+    ref0 = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, s_, pad).permute(0, 2, 3, 1)
+    assert float((y0.cpu().double() - ref0).norm() / ref0.norm()) < 6e-3
+    # dgrad with the input mask, accumulating into an existing tensor
+    dy = torch.randn(y.shape, generator=g)
+    base = torch.randn(B, H, W, Cin, generator=g)
+    out = base.clone().to(dev)
+    dx = O.conv_dgrad(dy.to(dev), wd, (B, H, W, Cin), k, s_, pad, in_mask=mask.to(dev), out=out)
+    xr = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    F.conv2d(xr, w.double(), None, s_, pad).backward(dy.permute(0, 3, 1, 2).double())
+    refdx = xr.grad.permute(0, 2, 3, 1) * mask[..., None].double() + base.double()
+    e2 = dx.cpu().double() - refdx
+    assert float(e2.norm() / refdx.norm()) < 6e-3, float(e2.norm() / refdx.norm())
+    # the switch really takes the bf16 path: results differ from the fp32 kernels by bf16-sized amounts
+    O.set_precision("f32")
+    y32 = O.conv_fwd(x.to(dev), wd, None, k, s_, pad)
+    rel = float((y0 - y32).double().norm() / y32.double().norm())
+    assert 1e-4 < rel < 6e-3, rel
+
+
+def test_wino16_gated_dgrad_and_determinism(dev):
+    """VGG-style dgrad with the fused ReLU-backward gate, twice: bitwise equal."""
+    import torch.nn.functional as F
+    from tg_hip import ops as O
+    g = torch.Generator().manual_seed(5)
+    B, H, W, C = 2, 48, 40, 64
+    w = (torch.randn(128, C, 3, 3, generator=g) / 24).contiguous(memory_format=torch.channels_last).to(dev)
+    dy = torch.randn(B, H, W, 128, generator=g).to(dev)
+    gate = torch.randn(B, H, W, C, generator=g).clamp_min(0).to(dev)
+    O.set_precision("bf16")
+    a = O.conv_dgrad(dy, w, (B, H, W, C), 3, 1, 1, gate=gate, gate_act=O.ACT_RELU)
+    b_ = O.conv_dgrad(dy, w, (B, H, W, C), 3, 1, 1, gate=gate, gate_act=O.ACT_RELU)
+    assert torch.equal(a, b_)
+    xr = torch.zeros(B, C, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, w.cpu().double(), None, 1, 1).backward(dy.cpu().permute(0, 3, 1, 2).double())
+    ref = xr.grad.permute(0, 2, 3, 1) * (gate.cpu() > 0).double()
+    assert float((a.cpu().double() - ref).norm() / ref.norm()) < 6e-3

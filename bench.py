@@ -109,6 +109,7 @@ def main():
 
     # before the first HIP call (torch.cuda.is_available() initialises the runtime): the host driver only supports dmabuf IPC
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("TERRAGAN_ALLOW_STANDIN_VGG", "1")      # no network: stand-in VGG16 weights (same FLOPs), see `data`
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -32,14 +32,26 @@ logger = logging.getLogger(__name__)
 _VGG16_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
 
 
-def _vgg16_features_16(vgg_weights=None):
+def _vgg16_features_16(vgg_weights=None, allow_standin=None):
+    """features[:16] of torchvision's VGG16.  Weights, in this order: `vgg_weights` / $TERRAGAN_VGG16_WEIGHTS (a local
+    torchvision vgg16 state-dict, keys `features.N.*` or `N.*`), torchvision's IMAGENET1K_V1 (what the reference loads,
+    losses.py:31), and -- ONLY when the caller opts in (`allow_standin=True` or $TERRAGAN_ALLOW_STANDIN_VGG=1: tests,
+    bench.py, smoke()) -- a deterministic default-initialised stand-in of the same architecture.  Without the opt-in a
+    missing trunk raises: a perceptual term on random features would silently optimise another objective than the reference."""
     path = vgg_weights or os.environ.get("TERRAGAN_VGG16_WEIGHTS")
+    if allow_standin is None:
+        allow_standin = os.environ.get("TERRAGAN_ALLOW_STANDIN_VGG") == "1"
     sd = None
     if path is None:
         try:  # pragma: no cover - torchvision is absent in the build image
             from torchvision.models import VGG16_Weights, vgg16
             return vgg16(weights=VGG16_Weights.IMAGENET1K_V1).features[:16]
-        except Exception:  # noqa: BLE001
+        except Exception as e:  # noqa: BLE001
+            if not allow_standin:
+                raise RuntimeError("InpaintingLoss: torchvision / the ImageNet VGG16 weights are unavailable (" + repr(e) + "). "
+                                   "Point TERRAGAN_VGG16_WEIGHTS (or vgg_weights=) at a local vgg16 state-dict, or opt in to "
+                                   "the deterministic stand-in trunk with allow_standin_vgg=True / "
+                                   "TERRAGAN_ALLOW_STANDIN_VGG=1 (same FLOPs, NOT the reference's objective).") from e
             logger.warning("torchvision / ImageNet VGG16 weights unavailable: using a deterministic stand-in "
                            "trunk (set TERRAGAN_VGG16_WEIGHTS to a local vgg16 state-dict for real weights)")
     else:
@@ -160,12 +172,12 @@ class _InpaintingLossFn(torch.autograd.Function):
 
 class InpaintingLoss(nn.Module):
     def __init__(self, perceptual_weight: float = 0.1, tv_weight: float = 0.1, boundary_weight: float = 0.5,
-                 device=None, vgg_weights=None):
+                 device=None, vgg_weights=None, allow_standin_vgg=None):
         super().__init__()
         self.device = device if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.l1_loss = _L1Mean()
         self.perceptual_weight, self.tv_weight, self.boundary_weight = perceptual_weight, tv_weight, boundary_weight
-        self.vgg_layers = _vgg16_features_16(vgg_weights).eval().to(self.device)
+        self.vgg_layers = _vgg16_features_16(vgg_weights, allow_standin_vgg).eval().to(self.device)
         for p in self.vgg_layers.parameters():
             p.requires_grad = False
         self.boundary_loss = BoundaryAwareLoss(device=self.device).to(self.device)

@@ -111,3 +111,39 @@ def test_bench_input_recipe_matches_oracle_copy():
         a, m = synth_batch(b, size, seed)
         a2, m2 = Orc.synth_batch(b, size, seed)
         assert torch.equal(a, a2) and torch.equal(m, m2)
+
+
+def test_vgg_trunk_weights_resolution(tmp_path, monkeypatch):
+    """losses.py:31-34: the reference loads torchvision's ImageNet VGG16.  Offline that cannot work: the mirror must (i) RAISE
+    unless the caller opts in to the stand-in trunk, (ii) load a local vgg16-format state-dict through
+    TERRAGAN_VGG16_WEIGHTS / vgg_weights=, keeping only features[:16] (keys `features.N.*`, N < 16)."""
+    import pytest
+    from mvp_gan.src.utils.losses import InpaintingLoss
+    monkeypatch.delenv("TERRAGAN_VGG16_WEIGHTS", raising=False)
+    monkeypatch.setenv("TERRAGAN_ALLOW_STANDIN_VGG", "0")
+    with pytest.raises(RuntimeError, match="TERRAGAN_VGG16_WEIGHTS"):
+        InpaintingLoss(0.1, 0.1, device=torch.device("cpu"))
+    InpaintingLoss(0.1, 0.1, device=torch.device("cpu"), allow_standin_vgg=True)           # explicit opt-in
+    # a synthetic torchvision-format vgg16 state-dict: all 13 convs + classifier keys
+    g = torch.Generator().manual_seed(3)
+    cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+    sd, idx, cin = {}, 0, 3
+    for v in cfg:
+        if v == "M":
+            idx += 1
+            continue
+        sd[f"features.{idx}.weight"] = torch.randn(v, cin, 3, 3, generator=g) * 0.01
+        sd[f"features.{idx}.bias"] = torch.randn(v, generator=g) * 0.01
+        idx, cin = idx + 2, v
+    sd["classifier.0.weight"], sd["classifier.0.bias"] = torch.zeros(4, 4), torch.zeros(4)
+    path = tmp_path / "vgg16.pth"
+    torch.save(sd, path)
+    monkeypatch.setenv("TERRAGAN_VGG16_WEIGHTS", str(path))
+    crit = InpaintingLoss(0.1, 0.1, device=torch.device("cpu"))
+    got = crit.vgg_layers.state_dict()
+    assert sorted(got) == sorted(f"{i}.{p}" for i in (0, 2, 5, 7, 10, 12, 14) for p in ("weight", "bias"))
+    for k, v in got.items():
+        assert torch.equal(v, sd["features." + k]), k
+    assert not any(p_.requires_grad for p_ in crit.vgg_layers.parameters())
+    crit2 = InpaintingLoss(0.1, 0.1, device=torch.device("cpu"), vgg_weights=str(path))   # explicit argument, same result
+    assert torch.equal(crit2.vgg_layers.state_dict()["14.weight"], sd["features.14.weight"])

@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("TERRAGAN_ALLOW_STANDIN_VGG", "1")   # dev tool: no ImageNet weights offline
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'terra-gan_amd'))
 import torch

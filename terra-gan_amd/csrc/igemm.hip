@@ -213,8 +213,8 @@ __device__ __forceinline__ size_t dst_pixel(const IGemmParams& p, int m) {
     return ((size_t)b * p.DH + (oy * p.ds + p.dy0)) * p.DW + (ox * p.ds + p.dx0);
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR, bool BF16 = false>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR, bool BF16>
+__device__ __forceinline__ void igemm_body(const IGemmParams& p, const int bz) {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, LDK = 36;
     constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= p.M) return;          // merged multi-class launch: the grid is sized for the largest class
     const int kc = tid & 7, r0 = tid >> 3;
 
     int rb[A_LOADS], ry[A_LOADS], rx[A_LOADS];
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
         rx[i] = ox * p.ss + p.sx0;
     }
 
-    const int t_begin = blockIdx.z * p.steps_per_split;
+    const int t_begin = bz * p.steps_per_split;
     const int t_end = min(p.T, t_begin + p.steps_per_split);
 
     f32x4 ra[A_LOADS], rw[B_LOADS];
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
                     const int nb = n0 + (wn * WN + j) * 32 + cc;
                     if (m >= p.M || nb >= p.N) return;
                     if (p.splits > 1) {
-                        *reinterpret_cast<f32x4*>(p.ws + ((size_t)blockIdx.z * p.M + m) * p.N + nb) = v4;
+                        *reinterpret_cast<f32x4*>(p.ws + ((size_t)bz * p.M + m) * p.N + nb) = v4;
                     } else {
                         const size_t pix = dst_pixel(p, m);
                         *reinterpret_cast<f32x4*>(p.dst + pix * p.N + nb) = epilogue4(p, v4, pix, nb);
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
                     const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
-                    if (n < p.N) p.ws[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
+                    if (n < p.N) p.ws[((size_t)bz * p.M + m) * p.N + n] = acc[i][j][r];
                 }
             } else {
                 const size_t pix = dst_pixel(p, m);
@@ -511,8 +512,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
     }
 }
 
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR, bool BF16 = false>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
+    igemm_body<WAVES_M, WAVES_N, WM, WN, SCALAR, BF16>(p, blockIdx.z);
+}
+// Up to 4 independent problems of one tile configuration in ONE launch (the parity classes of a stride-2 dgrad on a small
+// grid: four 17-us launches + four split-K epilogues per layer were pure launch latency): blockIdx.z = class * splits + split.
+struct IGemmMulti {
+    IGemmParams c[4];
+};
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool BF16>
+__global__ __launch_bounds__(256, 2) void igemm_multi_kernel(const IGemmMulti pm, const int splits) {
+    const int cls = blockIdx.z / splits;
+    igemm_body<WAVES_M, WAVES_N, WM, WN, false, BF16>(pm.c[cls], blockIdx.z - cls * splits);
+}
+
 // split-K second pass: fixed-order sum over the slabs + the same epilogue.
-__global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IGemmParams p) {
+__device__ __forceinline__ void splitk_epilogue_body(const IGemmParams& p) {
     const size_t total = (size_t)p.M * p.N;
     if ((p.N & 3) == 0) {
         const size_t t4 = total >> 2;
@@ -540,6 +556,9 @@ __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IGemmParams p
         *d = v;
     }
 }
+
+__global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IGemmParams p) { splitk_epilogue_body(p); }
+__global__ __launch_bounds__(256) void igemm_splitk_epilogue_multi(const IGemmMulti pm) { splitk_epilogue_body(pm.c[blockIdx.y]); }
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR, bool BF16 = false>
 static int launch_igemm_cfg(const IGemmParams& p, hipStream_t s) {
@@ -939,8 +958,11 @@ static bool try_pgemm(IGemmParams* ps, int ncls, size_t ws_floats_avail, hipStre
             while (smax > 1 && (size_t)smax * p.M * p.N > ws_floats_avail) --smax;
             splits = choose_splits(work, smax, 512);
         }
-    } else if (work < 256) {
-        return false;           // merged launch has no split-K: too small a grid goes class by class instead
+    } else {
+        // merged launch has no split-K: a grid below one full round of resident workgroups (2 per CU) goes to the
+        // gathered-row kernel instead, whose merged launch splits K (enc4 dgrad: 256 patch workgroups ran at 50 TF)
+        static const int min_work = getenv("TG_PGEMM_MERGE_MIN") ? atoi(getenv("TG_PGEMM_MERGE_MIN")) : 512;
+        if (work < min_work) return false;
     }
     q.chunks_per_split = cdiv(p.nchunks, splits);
     p.splits = cdiv(p.nchunks, q.chunks_per_split);
@@ -1005,6 +1027,74 @@ static int launch_igemm(IGemmParams& p, hipStream_t s, size_t ws_floats_avail = 
     if (bn == 128) return launch_igemm_cfg<2, 2, 2, 2, false>(p, s);
     if (bn == 64) return launch_igemm_cfg<2, 2, 2, 1, false>(p, s);
     return launch_igemm_cfg<4, 1, 1, 1, false>(p, s);
+}
+
+// The parity classes of a strided dgrad that the patch kernel does not take (small grids: enc4-7) as ONE gathered-row
+// launch + ONE split-K epilogue launch.  All classes share the tile configuration and the split count; a class with fewer K
+// steps than splits leaves its surplus slabs zero.  Returns false when the classes do not qualify (caller goes class by class).
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool BF16>
+static int launch_igemm_multi_cfg(const IGemmMulti& pm, int ncls, int splits, hipStream_t s) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * (BF16 ? 40 * 2 : 36 * sizeof(float));
+    static LdsOptIn opt;
+    auto kern = igemm_multi_kernel<WAVES_M, WAVES_N, WM, WN, BF16>;
+    if (int rc = lds_opt_in(opt, reinterpret_cast<const void*>(kern), lds, "igemm multi")) return rc;
+    int mmax = 0;
+    double flops = 0, by = 0;
+    for (int i = 0; i < ncls; ++i) {
+        const IGemmParams& p = pm.c[i];
+        mmax = p.M > mmax ? p.M : mmax;
+        flops += 2.0 * p.M * (double)p.N * p.Ktot;
+        by += 4.0 * ((double)p.M + (double)p.N * p.Ktot + (double)p.M * p.N);
+    }
+    by += 4.0 * (double)pm.c[0].B * pm.c[0].IH * pm.c[0].IW * pm.c[0].C;
+    dim3 grid(cdiv(mmax, BM), cdiv(pm.c[0].N, BN), ncls * splits);
+    {
+        ProfScope ps(s, BF16 ? 3 : 0, flops, by, mmax * ncls, pm.c[0].N, pm.c[0].Ktot, pm.c[0].C, splits, (BF16 ? 3000 : 0) + 500 + BN);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, pm, splits);
+    }
+    TG_CHECK_LAUNCH("igemm_multi_kernel");
+    if (splits > 1) {
+        hipLaunchKernelGGL(igemm_splitk_epilogue_multi, dim3(ew_grid((int64_t)mmax * pm.c[0].N / 4, 256), ncls), dim3(256), 0, s, pm);
+        TG_CHECK_LAUNCH("igemm_splitk_epilogue_multi");
+    }
+    return TG_OK;
+}
+static bool try_igemm_multi(IGemmParams* cls, int ncls, float* ws, size_t ws_floats, hipStream_t s, int* rc) {
+    static const bool off = getenv("TG_NO_IGEMM_MULTI") != nullptr;
+    if (off || ncls < 2 || ncls > 4) return false;
+    const int bn = pick_bn(cls[0].N);
+    if (bn != 128 && bn != 64) return false;
+    long tiles = 0;
+    int tmax = 0;
+    size_t mn = 0;
+    for (int i = 0; i < ncls; ++i) {
+        const IGemmParams& p = cls[i];
+        if (p.M <= 0 || p.N != cls[0].N || (p.C % 4) != 0 || p.bf16 != cls[0].bf16 || smallconv_fwd_applies(p) || p.T <= 0) return false;
+        tiles += (long)cdiv(p.M, 128) * cdiv(p.N, bn);
+        tmax = p.T > tmax ? p.T : tmax;
+        mn += (size_t)p.M * p.N;
+    }
+    int splits = 1;
+    if (tmax >= 8) {
+        int smax = tmax / 4 < 64 ? tmax / 4 : 64;
+        while (smax > 1 && (size_t)smax * mn > ws_floats) --smax;
+        splits = choose_splits(tiles, smax, 512);
+    }
+    IGemmMulti pm = {};
+    size_t off_f = 0;
+    for (int i = 0; i < ncls; ++i) {
+        IGemmParams& p = cls[i];
+        p.steps_per_split = cdiv(p.T, splits);
+        p.splits = splits;
+        p.ws = ws + off_f;
+        off_f += (size_t)splits * p.M * p.N;
+        pm.c[i] = p;
+    }
+    for (int i = ncls; i < 4; ++i) pm.c[i] = pm.c[0];
+    if (cls[0].bf16) *rc = bn == 128 ? launch_igemm_multi_cfg<2, 2, 2, 2, true>(pm, ncls, splits, s) : launch_igemm_multi_cfg<2, 2, 2, 1, true>(pm, ncls, splits, s);
+    else *rc = bn == 128 ? launch_igemm_multi_cfg<2, 2, 2, 2, false>(pm, ncls, splits, s) : launch_igemm_multi_cfg<2, 2, 2, 1, false>(pm, ncls, splits, s);
+    return true;
 }
 
 static int check_conv(const TgConv* g, const char* who) {
@@ -1392,6 +1482,8 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, flo
             IGemmParams tmp[4];
             for (int i = 0; i < ncls; ++i) tmp[i] = cls[i];
             if (try_pgemm(tmp, ncls, ws2_floats, s, &rc)) return rc;
+            for (int i = 0; i < ncls; ++i) tmp[i] = cls[i];
+            if (try_igemm_multi(tmp, ncls, ws2, ws2_floats, s, &rc)) return rc;
         }
         for (int i = 0; i < ncls; ++i) {
             plan_splits(cls[i], ws2_floats);

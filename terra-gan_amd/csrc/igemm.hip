@@ -977,6 +977,7 @@ static bool try_pgemm(IGemmParams* ps, int ncls, size_t ws_floats_avail, hipStre
 }
 
 #include "wino.inc"
+#include "wino2.inc"
 #include "wino16.inc"
 
 static int pick_bn(int N) { return N >= 128 && N % 128 == 0 ? 128 : (N > 32 ? 64 : 32); }
@@ -1004,7 +1005,7 @@ static int launch_igemm(IGemmParams& p, hipStream_t s, size_t ws_floats_avail = 
         ProfScope ps(s, 2, 2.0 * p.M * (double)p.N * p.Ktot, by, p.M, p.N, p.Ktot, p.C, 1, 2000);
         return smallconv_fwd_launch(p, s);
     }
-    if (wino_ok(p)) return launch_wino(p, ws_floats_avail, s);
+    if (wino_ok(p)) return wino2_on() ? launch_wino2(p, ws_floats_avail, s) : launch_wino(p, ws_floats_avail, s);
     if (wino16_ok(p)) return launch_wino16(p, ws_floats_avail, s);
     {
         int rc = TG_OK;
@@ -1433,7 +1434,7 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, flo
         p.wino_u = wt;
         p.wino_ready = prep;
         TG_REQUIRE(p.bf16 ? wino16_ok(p) : wino_ok(p), "tg_conv_dgrad: internal: Winograd geometry predicate mismatch");
-        return p.bf16 ? launch_wino16(p, ws2_floats, s) : launch_wino(p, ws2_floats, s);
+        return p.bf16 ? launch_wino16(p, ws2_floats, s) : (wino2_on() ? launch_wino2(p, ws2_floats, s) : launch_wino(p, ws2_floats, s));
     }
     if (prep <= 0) {
         hipLaunchKernelGGL(transpose_w_kernel, dim3(ew_grid((int64_t)g->Cout * taps * g->Cin, 256)), dim3(256), 0, s, w, wt,

@@ -294,6 +294,81 @@ __global__ __launch_bounds__(256) void to1conv64_kernel(const IGemmParams p) {
     }
 }
 
+
+// ---- 64 channels -> 1 channel, 3x3 stride 1, through an LDS patch ------------------------------------------------------------
+// to1conv64_kernel fetches every tap straight from global memory: 9 x the tensor goes through the texture path (L1 hits, but
+// 2.4 GB of TA traffic for `final`'s 268 MB: 2.2 TB/s algorithmic, 27 % of HBM).  Here a workgroup stages the (4+2) x (32+2)
+// pixel x 64 channel patch of a 4 x 32 output tile ONCE (52 KB; zero outside the image, mask pre-multiplied) and the nine
+// taps are 16-byte LDS reads of four neighbouring pixels = 1 KB contiguous per wave instruction (conflict-free).  Lane =
+// (pixel of a 4-pixel row segment, channel quad) and the 16-lane shuffle reduction are those of to1conv64_kernel.
+constexpr int T1_TH = 4, T1_TW = 32, T1_PH = T1_TH + 2, T1_PW = T1_TW + 2;
+__global__ __launch_bounds__(256) void to1conv64_lds_kernel(const IGemmParams p, int tiles_x, int tiles_y, int sy_min, int sx_min) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [T1_PH][T1_PW][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = lane >> 4, cq = lane & 15;
+    int tile = blockIdx.x;
+    const int txi = tile % tiles_x;
+    tile /= tiles_x;
+    const int tyi = tile % tiles_y, b = tile / tiles_y;
+    const int oy0 = tyi * T1_TH, ox0 = txi * T1_TW;
+    f32x4 w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        w[t] = *reinterpret_cast<const f32x4*>(p.wmat + (size_t)weight_tap(p, t / 3, t % 3) * 64 + 4 * cq);
+    // stage the patch: thread = (pixel slot, channel quad); all 13 loads of a thread in flight together
+    constexpr int NSLOT = T1_PH * T1_PW * 16, NIT = (NSLOT + 255) / 256;
+    f32x4 v[NIT];
+    float f[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int slot = threadIdx.x + 256 * it, pp = slot >> 4;
+        const int py = pp / T1_PW, px = pp - py * T1_PW;
+        const int iy = oy0 + sy_min + py, ix = ox0 + sx_min + px;
+        const bool in = slot < NSLOT && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        const size_t pix = in ? ((size_t)b * p.IH + iy) * p.IW + ix : 0;
+        v[it] = *reinterpret_cast<const f32x4*>(p.src + pix * 64 + 4 * (slot & 15));
+        f[it] = !in ? 0.f : (p.amask ? p.amask[pix] : 1.f);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int slot = threadIdx.x + 256 * it;
+        f32x4 o = v[it] * f[it];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = f[it] != 0.f ? o[k] : 0.f;
+        if (slot < NSLOT) *reinterpret_cast<f32x4*>(sm + 4 * slot) = o;
+    }
+    __syncthreads();
+    const float bias = p.bias ? p.bias[0] : 0.f;
+    const int oyy = p.sy0 - sy_min, oxx = p.sx0 - sx_min;
+    // wave w owns tile row w: 8 segments of 4 pixels
+#pragma unroll 2
+    for (int seg = 0; seg < T1_TW / 4; ++seg) {
+        const int tx_o = 4 * seg + e;
+        const float* pb = sm + (((wave + oyy) * T1_PW) + tx_o + oxx) * 64 + 4 * cq;
+        float acc = 0.f;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(pb + ((ty * p.tstep) * T1_PW + tx * p.tstep) * 64);
+                const f32x4 ww = w[ty * 3 + tx];
+                acc += x[0] * ww[0] + x[1] * ww[1] + x[2] * ww[2] + x[3] * ww[3];
+            }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        const int oy = oy0 + wave, ox = ox0 + tx_o;
+        if (cq == 0 && oy < p.OH && ox < p.OW) {
+            const size_t opix = out_pixel(p, b, oy, ox);
+            float r = acc + bias;
+            if (p.rowscale) r *= p.rowscale[opix];
+            r = apply_act(r, p.act, p.slope);
+            if (p.gate) r *= gate_factor(p, opix);
+            if (p.accumulate) r += p.dst[opix];
+            p.dst[opix] = r;
+        }
+    }
+}
+
 static bool to1_cfg_ok(int th, int tw) {
     return (th == 3 && tw == 3) || (th == 2 && tw == 2) || (th == 4 && tw == 4) || (th == 1 && tw == 1) || (th == 2 && tw == 1) ||
            (th == 1 && tw == 2);
@@ -342,6 +417,16 @@ int smallconv_fwd_launch(const IGemmParams& p, hipStream_t s) {
         else if (p.TH == 3 && p.TW == 3) hipLaunchKernelGGL((c1conv_kernel<3, 3>), grid, dim3(256), lds, s, p, q);
         else hipLaunchKernelGGL((c1conv_kernel<0, 0>), grid, dim3(256), lds, s, p, q);
         TG_CHECK_LAUNCH("c1conv_kernel");
+        return TG_OK;
+    }
+    static const bool no_lds = getenv("TG_NO_TO1LDS") != nullptr;
+    if (!no_lds && p.TH == 3 && p.TW == 3 && p.ss == 1 && (p.tstep == 1 || p.tstep == -1) && p.OH >= T1_TH && p.OW >= T1_TW) {
+        const int tiles_x = cdiv(p.OW, T1_TW), tiles_y = cdiv(p.OH, T1_TH);
+        const int sy_b = p.sy0 + 2 * p.tstep, sx_b = p.sx0 + 2 * p.tstep;
+        const int sy_min = p.sy0 < sy_b ? p.sy0 : sy_b, sx_min = p.sx0 < sx_b ? p.sx0 : sx_b;
+        const size_t lds = (size_t)T1_PH * T1_PW * 64 * sizeof(float);
+        hipLaunchKernelGGL(to1conv64_lds_kernel, dim3(tiles_x * tiles_y * p.B), dim3(256), lds, s, p, tiles_x, tiles_y, sy_min, sx_min);
+        TG_CHECK_LAUNCH("to1conv64_lds_kernel");
         return TG_OK;
     }
     int blocks = cdiv(p.M / 4, 4 * 4);
@@ -464,6 +549,86 @@ __global__ __launch_bounds__(256) void to1wgrad64_kernel(const WgradParams p, fl
     }
 }
 
+
+// Cout == 1, C == 64, 3x3 stride 1: the weight gradient through the same LDS patch (see to1conv64_lds_kernel).  Persistent
+// workgroups walk 4 x 32-pixel tiles and keep the 9 x 4-channel accumulators in registers; partial[block][tap][c].
+__global__ __launch_bounds__(256) void to1wgrad64_lds_kernel(const WgradParams p, float* __restrict__ partial, int tiles_x, int tiles_y,
+                                                             int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [T1_PH][T1_PW][64] + dy tile [T1_TH][T1_TW]
+    float* dys = sm + T1_PH * T1_PW * 64;
+    float* red = sm;                                                 // [4][9][64] after the tile loop
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = lane >> 4, cq = lane & 15;
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NSLOT = T1_PH * T1_PW * 16, NIT = (NSLOT + 255) / 256;
+    for (int tile0 = blockIdx.x; tile0 < ntiles; tile0 += gridDim.x) {
+        int tile = tile0;
+        const int txi = tile % tiles_x;
+        tile /= tiles_x;
+        const int tyi = tile % tiles_y, b = tile / tiles_y;
+        const int oy0 = tyi * T1_TH, ox0 = txi * T1_TW;
+        f32x4 v[NIT];
+        float f[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int slot = threadIdx.x + 256 * it, pp = slot >> 4;
+            const int py = pp / T1_PW, px = pp - py * T1_PW;
+            const int iy = oy0 - p.pad + py, ix = ox0 - p.pad + px;
+            const bool in = slot < NSLOT && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const size_t pix = in ? ((size_t)b * p.H + iy) * p.W + ix : 0;
+            v[it] = *reinterpret_cast<const f32x4*>(p.x + pix * 64 + 4 * (slot & 15));
+            f[it] = !in ? 0.f : (p.amask ? p.amask[pix] : 1.f);
+        }
+        float dyv = 0.f;
+        if (threadIdx.x < T1_TH * T1_TW) {
+            const int oy = oy0 + threadIdx.x / T1_TW, ox = ox0 + threadIdx.x % T1_TW;
+            if (oy < p.Ho && ox < p.Wo) dyv = p.dy[((size_t)b * p.Ho + oy) * p.Wo + ox];
+        }
+        __syncthreads();                     // the previous tile's readers are done
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int slot = threadIdx.x + 256 * it;
+            f32x4 o = v[it] * f[it];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = f[it] != 0.f ? o[k] : 0.f;
+            if (slot < NSLOT) *reinterpret_cast<f32x4*>(sm + 4 * slot) = o;
+        }
+        if (threadIdx.x < T1_TH * T1_TW) dys[threadIdx.x] = dyv;
+        __syncthreads();
+#pragma unroll 2
+        for (int seg = 0; seg < T1_TW / 4; ++seg) {
+            const int tx_o = 4 * seg + e;
+            const float d = dys[wave * T1_TW + tx_o];
+            const float* pb = sm + ((wave * T1_PW) + tx_o) * 64 + 4 * cq;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    acc[ky * 3 + kx] += d * *reinterpret_cast<const f32x4*>(pb + (ky * T1_PW + kx) * 64);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float vv = acc[t][j];
+            vv += __shfl_xor(vv, 16, 64);
+            vv += __shfl_xor(vv, 32, 64);
+            acc[t][j] = vv;
+        }
+        if (e == 0) *reinterpret_cast<f32x4*>(&red[(wave * 9 + t) * 64 + 4 * cq]) = acc[t];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * 64; i += 256) {
+        const int t = i >> 6, c = i & 63;
+        partial[((size_t)blockIdx.x * 9 + t) * 64 + c] = red[(0 * 9 + t) * 64 + c] + red[(1 * 9 + t) * 64 + c] + red[(2 * 9 + t) * 64 + c] +
+                                                         red[(3 * 9 + t) * 64 + c];
+    }
+}
+
 // second stage of the small wgrad kernels: ONE WAVE per output element -- lane l sums partial blocks l, l+64, ... (four
 // independent loads per trip), then a fixed xor tree over the lanes: deterministic, and the ~1000 partials of an element
 // are no longer a serial chain of dependent loads (that cost 74 us for 576 outputs)
@@ -497,6 +662,10 @@ static int c1_wgrad_blocks(const WgradParams& p) {
     return tiles < 512 ? tiles : 512;
 }
 
+static bool to1_wgrad_lds_ok(const WgradParams& p) {
+    static const bool off = getenv("TG_NO_TO1LDS") != nullptr;
+    return !off && p.Cout == 1 && p.C == 64 && p.k == 3 && p.stride == 1 && p.pad == 1 && p.Ho >= T1_TH && p.Wo >= T1_TW;
+}
 bool smallconv_wgrad_applies(const WgradParams& p) {
     if (getenv("TG_NO_SMALLCONV")) return false;
     // Cin == 1 weight gradients measured faster on the MFMA wgrad kernel's scalar-gather path (0.11 vs 0.27 ms for
@@ -506,7 +675,7 @@ bool smallconv_wgrad_applies(const WgradParams& p) {
     return false;
 }
 size_t smallconv_wgrad_ws_floats(const WgradParams& p) {
-    const int blocks = p.C == 1 ? c1_wgrad_blocks(p) : to1_wgrad_blocks(p);
+    const int blocks = p.C == 1 ? c1_wgrad_blocks(p) : (to1_wgrad_lds_ok(p) ? 768 : to1_wgrad_blocks(p));
     return (size_t)blocks * p.Cout * p.k * p.k * p.C + 64;
 }
 int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream_t s) {
@@ -525,6 +694,12 @@ int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream
         else if (p.k == 4) hipLaunchKernelGGL((c1wgrad_kernel<4>), grid, dim3(256), lds, s, p, q, ntiles, ws);
         else hipLaunchKernelGGL((c1wgrad_kernel<3>), grid, dim3(256), lds, s, p, q, ntiles, ws);
         TG_CHECK_LAUNCH("c1wgrad_kernel");
+    } else if (to1_wgrad_lds_ok(p)) {
+        const int tiles_x = cdiv(p.Wo, T1_TW), tiles_y = cdiv(p.Ho, T1_TH), ntiles = tiles_x * tiles_y * p.B;
+        nb = ntiles < 768 ? ntiles : 768;           // 3 resident workgroups per CU (52 KB of LDS each)
+        const size_t lds = ((size_t)T1_PH * T1_PW * 64 + T1_TH * T1_TW) * sizeof(float);
+        hipLaunchKernelGGL(to1wgrad64_lds_kernel, dim3(nb), dim3(256), lds, s, p, ws, tiles_x, tiles_y, ntiles);
+        TG_CHECK_LAUNCH("to1wgrad64_lds_kernel");
     } else {
         const int quads = p.Mpix / 4;
         const int blocks = to1_wgrad_blocks(p);

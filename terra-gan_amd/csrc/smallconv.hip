@@ -493,6 +493,96 @@ __global__ __launch_bounds__(256) void c1wgrad_kernel(const WgradParams p, const
     }
 }
 
+
+// Cin == 1 weight gradient on the fp32 MFMA: dW[co][tap] = sum_pix dy[pix][co] * x[pix @ tap] is a GEMM with M = 64 output
+// channels, N = taps (padded to 32s), K = pixels.  A[co][pix] is read straight from dy (a lane's 4 bytes are part of a
+// coalesced 128-byte row of 32 channels), B[pix][tap] is the im2col view of the 1-channel LDS patch (one ds_read_b32 per lane:
+// lane = tap, lane half = one of the step's two pixels).  The scalar-gather path of the generic wgrad kernel ran this at
+// 0.7 TB/s (enc1: 113 us for 67 MB of dy; D conv0: 140 us for 134 MB).  Persistent workgroups over 16x16 output tiles,
+// 4 waves x 64 pixels each; partial[block][co][tap], reduced by smallconv_slab_reduce in fixed order (deterministic).
+template <int K>
+__global__ __launch_bounds__(256) void c1wgrad_mfma_kernel(const WgradParams p, const C1Geom q, int ntiles, float* __restrict__ partial) {
+    constexpr int NT = K * K, NTT = (NT + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* patch = sm;                                  // [PH*PW]
+    float* red = sm + ((q.PH * q.PW + 3) & ~3);         // [64][NTT*32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, li = lane & 31;
+    const int co0 = blockIdx.y * 64;
+    int tapoff[NTT];
+    bool tapok[NTT];
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) {
+        const int tap = 32 * t + li;
+        tapok[t] = tap < NT;
+        const int tt = tapok[t] ? tap : 0;
+        tapoff[t] = (tt / K) * q.PW + (tt % K);
+    }
+    f32x16 acc[2][NTT];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < NTT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+    for (int tile0 = blockIdx.x; tile0 < ntiles; tile0 += gridDim.x) {
+        int tile = tile0;
+        const int txi = tile % q.tiles_x;
+        tile /= q.tiles_x;
+        const int tyi = tile % q.tiles_y, b = tile / q.tiles_y;
+        const int oy0 = tyi * C1_T, ox0 = txi * C1_T;
+        __syncthreads();
+        c1_stage_patch(p.x, p.amask, patch, b, oy0 * p.stride - p.pad, ox0 * p.stride - p.pad, q.PH, q.PW, p.H, p.W);
+        __syncthreads();
+        // this wave's 64 pixels: rows 4*wave .. 4*wave+3, 16 columns; K step s = pixels 2s, 2s+1 (lane half h)
+#pragma unroll
+        for (int s8 = 0; s8 < 4; ++s8) {
+            float a[8][2], bv[8][NTT];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = 8 * s8 + u;
+                const int ty_o = wave * 4 + (s >> 3), tx_o = ((2 * s) & 15) + h;
+                const int oy = oy0 + ty_o, ox = ox0 + tx_o;
+                const bool in = oy < p.Ho && ox < p.Wo;
+                const float* dp = p.dy + (((size_t)b * p.Ho + (in ? oy : 0)) * p.Wo + (in ? ox : 0)) * p.Cout + co0 + li;
+                a[u][0] = in ? dp[0] : 0.f;
+                a[u][1] = in ? dp[32] : 0.f;
+                const int pbase = ty_o * p.stride * q.PW + tx_o * p.stride;
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) bv[u][t] = tapok[t] ? patch[pbase + tapoff[t]] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][c], bv[u][t], acc[c][t], 0, 0, 0);
+        }
+    }
+    // cross-wave reduction in a fixed order (wave 0 stores, waves 1..3 add), then partial[block][co][tap]
+    constexpr int RP = NTT * 32 + 1;
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int t = 0; t < NTT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        float* d = red + co * RP + 32 * t + li;
+                        *d = w == 0 ? acc[c][t][r] : *d + acc[c][t][r];
+                    }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * NT; i += 256) {
+        const int co = i / NT, tap = i - co * NT;
+        partial[((size_t)blockIdx.x * p.Cout + co0 + co) * NT + tap] = red[co * RP + tap];
+    }
+}
+
 // Cout == 1, C == 64: dW[tap][c] = sum_pix dy[pix] * x[pix@tap][c]; lane = (pixel of a 4-pixel row segment, channel quad)
 template <int K>
 __global__ __launch_bounds__(256) void to1wgrad64_kernel(const WgradParams p, float* __restrict__ partial, int quads_per_block) {
@@ -670,7 +760,7 @@ bool smallconv_wgrad_applies(const WgradParams& p) {
     if (getenv("TG_NO_SMALLCONV")) return false;
     // Cin == 1 weight gradients measured faster on the MFMA wgrad kernel's scalar-gather path (0.11 vs 0.27 ms for
     // enc1 at 256^2/B=16); the dedicated kernel stays available behind TG_C1WGRAD=1 for experiments.
-    if (p.C == 1 && p.Cout >= 64 && p.Cout % 64 == 0 && (p.k == 3 || p.k == 4 || p.k == 7) && getenv("TG_C1WGRAD")) return true;
+    if (p.C == 1 && p.Cout >= 64 && p.Cout % 64 == 0 && (p.k == 3 || p.k == 4 || p.k == 7) && !getenv("TG_NO_C1WGRAD_MFMA")) return true;
     if (p.Cout == 1 && p.C == 64 && (p.Wo % 4) == 0 && (p.k == 3 || p.k == 4)) return true;
     return false;
 }
@@ -689,11 +779,20 @@ int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream
         const int ntiles = q.tiles_x * q.tiles_y * p.B;
         nb = c1_wgrad_blocks(p);
         dim3 grid(nb, p.Cout / 64);
+        if (!getenv("TG_C1WGRAD")) {                 // default: the MFMA kernel
+            const int ntt = (p.k * p.k + 31) / 32;
+            const size_t lds = (((size_t)q.PH * q.PW + 3) / 4 * 4 + (size_t)64 * (ntt * 32 + 1)) * sizeof(float);
+            if (p.k == 7) hipLaunchKernelGGL((c1wgrad_mfma_kernel<7>), grid, dim3(256), lds, s, p, q, ntiles, ws);
+            else if (p.k == 4) hipLaunchKernelGGL((c1wgrad_mfma_kernel<4>), grid, dim3(256), lds, s, p, q, ntiles, ws);
+            else hipLaunchKernelGGL((c1wgrad_mfma_kernel<3>), grid, dim3(256), lds, s, p, q, ntiles, ws);
+            TG_CHECK_LAUNCH("c1wgrad_mfma_kernel");
+        } else {
         const size_t lds = (((size_t)q.PH * q.PW + 3) / 4 * 4 + (size_t)4 * p.k * 64) * sizeof(float);
         if (p.k == 7) hipLaunchKernelGGL((c1wgrad_kernel<7>), grid, dim3(256), lds, s, p, q, ntiles, ws);
         else if (p.k == 4) hipLaunchKernelGGL((c1wgrad_kernel<4>), grid, dim3(256), lds, s, p, q, ntiles, ws);
         else hipLaunchKernelGGL((c1wgrad_kernel<3>), grid, dim3(256), lds, s, p, q, ntiles, ws);
         TG_CHECK_LAUNCH("c1wgrad_kernel");
+        }
     } else if (to1_wgrad_lds_ok(p)) {
         const int tiles_x = cdiv(p.Wo, T1_TW), tiles_y = cdiv(p.Ho, T1_TH), ntiles = tiles_x * tiles_y * p.B;
         nb = ntiles < 768 ? ntiles : 768;           // 3 resident workgroups per CU (52 KB of LDS each)

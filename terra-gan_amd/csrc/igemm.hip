@@ -1115,7 +1115,9 @@ static bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // room for the Winograd-transformed weights of a stride-1 3x3 layer (0 when the layer can never take that path)
+#include "wino22.inc"
 static size_t conv_wino_floats(const TgConv* g) {
+    if (wino22_fwd_geom_ok(g) || wino22_dgrad_geom_ok(g)) return wino22_u_floats(g);
     if (g->k != 3 || g->stride != 1 || (g->Cin % 8) != 0 || (g->Cout % 8) != 0) return 0;
     return align_up(wino_u_floats(g->Cout, g->Cin), 64);
 }
@@ -1237,7 +1239,7 @@ extern "C" size_t tg_conv_wprep_bytes(const TgConv* g, int mode) {
         const TgConv g2 = s2d_geom(g);
         return s2d_w_floats(g) * sizeof(float) + tg_conv_wprep_bytes(&g2, mode);
     }
-    if (mode == TG_WPREP_FWD) return wino_fwd_geom_ok(g) ? conv_wino_floats(g) * sizeof(float) : 0;
+    if (mode == TG_WPREP_FWD) return wino_fwd_geom_ok(g) || wino22_fwd_geom_ok(g) ? conv_wino_floats(g) * sizeof(float) : 0;
     if (mode == TG_WPREP_DGRAD) return dgrad_wt_floats(g) * sizeof(float);
     return 0;
 }
@@ -1286,6 +1288,17 @@ static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, 
     p.T = (p.C % 4) ? cdiv(p.Ktot, 32) : p.TH * p.TW * p.nchunks;
     size_t ws_floats = ws ? ws_bytes / sizeof(float) : 0;
     const size_t uf = conv_wino_floats(g);
+    if (wino22_fwd_geom_ok(g) && (prep || (ws_floats >= uf && aligned16(ws)))) {
+        // 4x4 stride 2: Winograd F(2x2,2x2) over the shifted space-to-depth view, gathered on the fly (wino22.inc)
+        p.w_raw = w;
+        p.wino_u = prep ? wprep : ws;
+        p.wino_ready = prep;
+        if (!prep) {
+            p.ws = ws + uf;
+            ws_floats -= uf;
+        }
+        return launch_wino22(g, p, 0, ws_floats, (hipStream_t)stream);
+    }
     if (wino_fwd_geom_ok(g) && (prep || (ws_floats >= uf && aligned16(ws)))) {
         // transformed weights: prepared by the caller, or at the head of the workspace
         p.w_raw = w; p.w_sn = (long)p.Kfull; p.w_sk = 1; p.w_stap = g->Cin;
@@ -1435,6 +1448,17 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, flo
         p.wino_ready = prep;
         TG_REQUIRE(p.bf16 ? wino16_ok(p) : wino_ok(p), "tg_conv_dgrad: internal: Winograd geometry predicate mismatch");
         return p.bf16 ? launch_wino16(p, ws2_floats, s) : (wino2_on() ? launch_wino2(p, ws2_floats, s) : launch_wino(p, ws2_floats, s));
+    }
+    if (wino22_dgrad_geom_ok(g)) {
+        // 4x4 stride 2: the four parity classes as Winograd F(2x2,2x2) problems in one launch (wino22.inc)
+        IGemmParams p = {};
+        p.src = dy; p.rowscale = in_mask; p.dst = dx; p.ws = ws2;
+        p.act = TG_ACT_NONE; p.accumulate = accumulate;
+        p.gate = gate; p.gate_act = gate_act; p.gate_slope = gate_slope;
+        p.w_raw = w;
+        p.wino_u = wt;
+        p.wino_ready = prep;
+        return launch_wino22(g, p, 1, ws2_floats, s);
     }
     if (prep <= 0) {
         hipLaunchKernelGGL(transpose_w_kernel, dim3(ew_grid((int64_t)g->Cout * taps * g->Cin, 256)), dim3(256), 0, s, w, wt,

@@ -192,3 +192,86 @@ def test_s2d_5x5_stride2(dev, case):
     dw, db = O.conv_wgrad(x.to(dev), dy.to(dev), wd, 5, 2, 2, in_mask=mask.to(dev))
     assert (dw.cpu().double() - refdw).abs().max().item() <= 3e-6 * refdw.abs().max().item() + 1e-5, case
     assert torch.allclose(db.cpu().double(), dy.double().sum((0, 1, 2)), atol=1e-3, rtol=1e-5)
+
+
+# ---- F(2x2,2x2): the discriminator's 4x4 / stride-2 / pad-1 convolutions (wino22.inc) ---------------------------------------
+# B, H, W, Cin, Cout
+W22_CASES = [
+    (2, 32, 32, 64, 128),
+    (1, 64, 32, 8, 64),          # one 8-channel step per parity phase
+    (3, 36, 44, 24, 64),         # ragged: 18 x 22 outputs = 1.1 x 1.4 patches
+    (2, 32, 32, 256, 64),        # K = 1024 -> split-K slabs
+    (1, 128, 128, 64, 128),      # the d2 geometry at batch 1
+    (4, 32, 32, 128, 256),
+]
+
+
+@pytest.mark.parametrize("case", W22_CASES)
+def test_wino22_fwd(dev, case):
+    from tg_hip import ops as O
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 4, 4, generator=g) / (4 * Cin ** 0.5)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    mask = (torch.rand(B, H, W, generator=g) > 0.3).float()
+    wd = w.contiguous(memory_format=torch.channels_last).to(dev)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), bias.double(), 2, 1).permute(0, 2, 3, 1)
+    y = O.conv_fwd(x.to(dev), wd, bias.to(dev), 4, 2, 1)
+    tol = 2e-6 * max(1.0, ref.abs().max().item()) * (Cin / 16) ** 0.5 + 3e-6
+    assert (y.cpu().double() - ref).abs().max().item() <= tol, case
+    # masked input + LeakyReLU epilogue
+    refm = F.conv2d((x * mask[..., None]).permute(0, 3, 1, 2).double(), w.double(), bias.double(), 2, 1).permute(0, 2, 3, 1)
+    refm = torch.where(refm > 0, refm, 0.2 * refm)
+    ym = O.conv_fwd(x.to(dev), wd, bias.to(dev), 4, 2, 1, in_mask=mask.to(dev), act=O.ACT_LEAKY, slope=0.2)
+    assert (ym.cpu().double() - refm).abs().max().item() <= tol, case
+    assert torch.equal(y, O.conv_fwd(x.to(dev), wd, bias.to(dev), 4, 2, 1))
+
+
+@pytest.mark.parametrize("case", W22_CASES)
+def test_wino22_dgrad(dev, case):
+    from tg_hip import ops as O
+    B, H, W, Cout, Cin = case          # swapped: dgrad's output channels (Cin) must be a multiple of 64
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    Ho, Wo = H // 2, W // 2
+    dy = torch.randn(B, Ho, Wo, Cout, generator=g)
+    w = torch.randn(Cout, Cin, 4, 4, generator=g) / (4 * Cout ** 0.5)
+    mask = (torch.rand(B, H, W, generator=g) > 0.3).float()
+    xact = torch.randn(B, H, W, Cin, generator=g)
+    wd = w.contiguous(memory_format=torch.channels_last).to(dev)
+    ref = F.conv_transpose2d(dy.permute(0, 3, 1, 2).double(), w.double(), None, 2, 1).permute(0, 2, 3, 1)
+    dx = O.conv_dgrad(dy.to(dev), wd, (B, H, W, Cin), 4, 2, 1)
+    tol = 2e-6 * max(1.0, ref.abs().max().item()) * (Cout / 16) ** 0.5 + 3e-6
+    assert (dx.cpu().double() - ref).abs().max().item() <= tol, case
+    base = torch.randn(B, H, W, Cin, generator=g)
+    out = base.clone().to(dev)
+    O.conv_dgrad(dy.to(dev), wd, (B, H, W, Cin), 4, 2, 1, in_mask=mask.to(dev), out=out)
+    ref2 = base.double() + ref * mask[..., None].double()
+    assert (out.cpu().double() - ref2).abs().max().item() <= tol, case
+    dxg = O.conv_dgrad(dy.to(dev), wd, (B, H, W, Cin), 4, 2, 1, gate=xact.to(dev), gate_act=O.ACT_LEAKY, gate_slope=0.2)
+    ref3 = ref * torch.where(xact > 0, 1.0, 0.2).double()
+    assert (dxg.cpu().double() - ref3).abs().max().item() <= tol, case
+    assert torch.equal(dx, O.conv_dgrad(dy.to(dev), wd, (B, H, W, Cin), 4, 2, 1))
+
+
+def test_wino22_is_the_kernel_that_runs(dev, tmp_path):
+    """The discriminator's 64->128 layer must go through wino22_kernel (launch tag 4022), forward and dgrad."""
+    import csv
+    from tg_hip import lib as L, ops as O
+    lib = L.load()
+    x = torch.randn(2, 64, 64, 64, device=dev)
+    w = (torch.randn(128, 64, 4, 4, device=dev) * 0.03).contiguous(memory_format=torch.channels_last)
+    b = torch.zeros(128, device=dev)
+    for kind in (0, 1, 2, 3):          # drop records of earlier tests
+        lib.tg_prof_summary(kind, None, None, None, None)
+    lib.tg_prof_enable(1)
+    y = O.conv_fwd(x, w, b, 4, 2, 1)
+    O.conv_dgrad(y, w, (2, 64, 64, 64), 4, 2, 1)
+    torch.cuda.synchronize()
+    lib.tg_prof_enable(0)
+    path = str(tmp_path / "launches.csv")
+    assert lib.tg_prof_dump(path.encode()) == 0
+    tags = [(r["kind"], r["cfg"]) for r in csv.DictReader(open(path))]
+    for kind in (0, 1, 2, 3):
+        lib.tg_prof_summary(kind, None, None, None, None)
+    assert tags.count(("0", "4022")) == 2, tags

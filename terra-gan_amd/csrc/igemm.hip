@@ -2020,6 +2020,8 @@ extern "C" size_t tg_conv_wgrad_ws_bytes(const TgConv* g) {
     {
         size_t wf = align_up(wino_wgrad_ws_floats(g), 64);
         if (wf > slabs) slabs = wf;
+        wf = align_up(wino22_wgrad_ws_floats(g), 64);
+        if (wf > slabs) slabs = wf;
     }
     if (s2d_ok(g)) {
         const TgConv g2 = s2d_geom(g);
@@ -2098,6 +2100,16 @@ extern "C" int tg_conv_wgrad(const TgConv* g, const float* x, const float* in_ma
         if (rc) return rc;
         if (db) {
             float* ws2 = ws + align_up(wino_wgrad_ws_floats(g), 64);
+            rc = tg_colsum_launch(dy, (int64_t)p.Mpix, g->Cout, db, ws2, s);
+            if (rc) return rc;
+        }
+        return TG_OK;
+    }
+    if (wino22_wgrad_ok(g, in_mask)) {        // 4x4 stride 2, 64-multiples of channels: Winograd F(2x2,2x2)
+        rc = launch_wino22_wgrad(g, p, dw, ws, s);
+        if (rc) return rc;
+        if (db) {
+            float* ws2 = ws + align_up(wino22_wgrad_ws_floats(g), 64);
             rc = tg_colsum_launch(dy, (int64_t)p.Mpix, g->Cout, db, ws2, s);
             if (rc) return rc;
         }

@@ -255,7 +255,8 @@ def test_wino22_dgrad(dev, case):
 
 
 def test_wino22_is_the_kernel_that_runs(dev, tmp_path):
-    """The discriminator's 64->128 layer must go through wino22_kernel (launch tag 4022), forward and dgrad."""
+    """The discriminator's 64->128 layer must go through wino22_kernel (launch tag 4022), forward and dgrad, and its
+    weight gradient through wino22_wgrad_kernel (4122)."""
     import csv
     from tg_hip import lib as L, ops as O
     lib = L.load()
@@ -267,6 +268,7 @@ def test_wino22_is_the_kernel_that_runs(dev, tmp_path):
     lib.tg_prof_enable(1)
     y = O.conv_fwd(x, w, b, 4, 2, 1)
     O.conv_dgrad(y, w, (2, 64, 64, 64), 4, 2, 1)
+    O.conv_wgrad(x, y, w, 4, 2, 1)
     torch.cuda.synchronize()
     lib.tg_prof_enable(0)
     path = str(tmp_path / "launches.csv")
@@ -274,4 +276,32 @@ def test_wino22_is_the_kernel_that_runs(dev, tmp_path):
     tags = [(r["kind"], r["cfg"]) for r in csv.DictReader(open(path))]
     for kind in (0, 1, 2, 3):
         lib.tg_prof_summary(kind, None, None, None, None)
-    assert tags.count(("0", "4022")) == 2, tags
+    assert tags.count(("0", "4022")) == 2 and ("1", "4122") in tags, tags
+
+
+# B, H, W, Cin, Cout
+W22_WGRAD_CASES = [
+    (2, 32, 32, 64, 64),
+    (1, 64, 32, 64, 128),
+    (3, 36, 44, 128, 64),        # ragged strips: 22 outputs = 1.4 strips; 18 rows = 9 tile rows
+    (4, 64, 64, 64, 128),        # split-K over strips
+    (2, 32, 32, 256, 128),
+]
+
+
+@pytest.mark.parametrize("case", W22_WGRAD_CASES)
+def test_wino22_wgrad(dev, case):
+    from tg_hip import ops as O
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case) + 2)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    dy = torch.randn(B, H // 2, W // 2, Cout, generator=g)
+    w = torch.zeros(Cout, Cin, 4, 4).contiguous(memory_format=torch.channels_last).to(dev)
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Cout, Cin, 4, 4), dy.permute(0, 3, 1, 2).double(),
+                                      stride=2, padding=1)
+    dw, db = O.conv_wgrad(x.to(dev), dy.to(dev), w, 4, 2, 1)
+    err = (dw.cpu().double() - ref).abs().max().item()
+    assert err <= 3e-6 * ref.abs().max().item() + 1e-5, (case, err, ref.abs().max().item())
+    assert torch.allclose(db.cpu().double(), dy.double().sum((0, 1, 2)), atol=1e-3, rtol=1e-5)
+    dw2, _ = O.conv_wgrad(x.to(dev), dy.to(dev), w, 4, 2, 1)
+    assert torch.equal(dw, dw2)          # deterministic split-K reduction

@@ -23,7 +23,8 @@ Roofline fields (every one can be recomputed from profiles/*_conv_launches.csv +
   frac              achieved / 157.3 TF (fp32-MFMA dense peak) -- the share of the matrix pipe that is busy, <= 1
   effective_tflops  algorithmic (direct-convolution) FLOPs / kernel time -- what the layer would need on a direct kernel
   layers            per-layer lines for the full-resolution PConv layers the 40 %-of-HBM target is about (enc1, dec1,
-                    dec2, final): alg_GBps / frac_hbm against 8 TB/s next to tflops / frac_mfma of the same launches
+                    dec2, final) and the discriminator's 4x4 stride-2 layers (d2, d5, d8: Winograd F(2x2,2x2), 9 multiplies
+                    where the direct convolution has 16): alg_GBps / frac_hbm against 8 TB/s next to tflops / frac_mfma
 """
 import argparse
 import ctypes as C
@@ -205,13 +206,17 @@ def main():
         for kind in (0, 1, 2, 3):
             prof_summary(lib, kind)                       # consume the records
 
-        WINO = ("4064", "4164")                           # Winograd kernels execute 16/36 of the algorithmic multiplies
+        WINO = ("4064", "4164")                           # Winograd F(2x2,3x3) kernels execute 16/36 of the algorithmic multiplies
+        WINO22 = ("4022", "4122")                         # F(2x2,2x2) (the 4x4 stride-2 convs of D): 9/16
+
+        def executed(r):
+            return float(r["gflop"]) / (2.25 if r["cfg"] in WINO else 16.0 / 9.0 if r["cfg"] in WINO22 else 1.0)
 
         def agg(pred):
             sel = [r for r in rows if pred(r)]
             ms = sum(float(r["ms"]) for r in sel)
             fl = sum(float(r["gflop"]) for r in sel) * 1e9
-            ex = sum(float(r["gflop"]) / (2.25 if r["cfg"] in WINO else 1.0) for r in sel) * 1e9
+            ex = sum(executed(r) for r in sel) * 1e9
             return ms, len(sel), fl, sum(float(r["alg_mb"]) for r in sel) * 1e6, ex
 
         def line(pred):
@@ -270,6 +275,8 @@ def main():
                            ("direct_pgemm_256x64_tile", lambda r: r["kind"] == "0" and r["cfg"] == "1064"),
                            ("wgrad_mfma_all", lambda r: r["kind"] == "1"),
                            ("wgrad_winograd_3x3", lambda r: r["kind"] == "1" and r["cfg"] == "4164"),
+                           ("d_4x4s2_winograd_2x2_fwd_dgrad", lambda r: r["cfg"] == "4022"),
+                           ("d_4x4s2_winograd_2x2_wgrad", lambda r: r["cfg"] == "4122"),
                            ("one_channel_convs_hbm", lambda r: r["kind"] == "2"),
                            ("bf16_operand_kernels", lambda r: r["kind"] == "3")]:
             d = line(pred)
@@ -278,7 +285,7 @@ def main():
         roofline["other_kernels"] = extra
         # the full-resolution partial-conv layers north_star's ">= 40 % of the memory roofline" is about, both ways
         layers = {}
-        for lname in ("enc1", "dec1", "dec2", "final"):
+        for lname in ("enc1", "dec1", "dec2", "final", "d2", "d5", "d8"):
             for part in ("fwd", "dgrad", "wgrad"):
                 d = line(lambda r, t=f"{lname}.{part}": r.get("tag") == t)
                 if d is not None:

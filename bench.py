@@ -206,7 +206,7 @@ def main():
         for kind in (0, 1, 2, 3):
             prof_summary(lib, kind)                       # consume the records
 
-        WINO = ("4064", "4164")                           # Winograd F(2x2,3x3) kernels execute 16/36 of the algorithmic multiplies
+        WINO = ("4064", "4164", "4016")                   # Winograd F(2x2,3x3) kernels execute 16/36 of the algorithmic multiplies
         WINO22 = ("4022", "4122")                         # F(2x2,2x2) (the 4x4 stride-2 convs of D): 9/16
 
         def executed(r):

@@ -16,6 +16,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //      7: + the 6 global loads (16 B per lane) of the step after next, feeding the writes
 //      8: as 7 with 6 writes only (the U image's 4 writes and their loads dropped)
 //      9: as 8 + the U image fetched by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write), waited for before the barrier
+//     10: mode 5 + 32 ds_write_b32 per wave (the transposing image writes of the wgrad kernels)
+//     11: mode 5 + 8 ds_write_b128 per wave (the same bytes)      12: mode 11 + 36 ds_read_b32 per wave
 template <int MODE>
 __global__ __launch_bounds__(512) void k(float* out, const float* in, int steps, const float* big, size_t big_floats) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -55,8 +57,8 @@ __global__ __launch_bounds__(512) void k(float* out, const float* in, int steps,
             constexpr int xi = t >> 2, e = t & 3;
             if constexpr (MODE >= 3 && t == 4) lds_barrier();
             if constexpr (MODE >= 2 && t == 26) lds_barrier();
-            if constexpr (MODE >= 6 && t < 2) *reinterpret_cast<f32x4*>(wdst + 2048 * t) = rg[t];
-            if constexpr (MODE >= 7 && t >= 2 && t < 4) rg[t - 2] = *reinterpret_cast<const f32x4*>(gc + 2048 * (t - 2));
+            if constexpr (MODE >= 6 && MODE <= 9 && t < 2) *reinterpret_cast<f32x4*>(wdst + 2048 * t) = rg[t];
+            if constexpr (MODE >= 7 && MODE <= 9 && t >= 2 && t < 4) rg[t - 2] = *reinterpret_cast<const f32x4*>(gc + 2048 * (t - 2));
             if constexpr (MODE >= 4 && t >= 5 && t < 9) {
                 td[t - 5] = *reinterpret_cast<const f32x4*>(tsrc + (t - 5) * 8);
                 td[4 + t - 5] = *reinterpret_cast<const f32x4*>(tsrc + 512 + (t - 5) * 8);
@@ -66,13 +68,19 @@ __global__ __launch_bounds__(512) void k(float* out, const float* in, int steps,
                 constexpr int kk = t - 14;
                 td[kk] = kk == 0 ? tt[0] - tt[2] : kk == 1 ? tt[1] + tt[2] : kk == 2 ? tt[2] - tt[1] : tt[1] - tt[3];
             }
-            if constexpr (MODE >= 6 && t >= 14 && t < 18) *reinterpret_cast<f32x4*>(wdst + 512 * (t - 14)) = td[t - 14];
+            if constexpr (MODE >= 6 && MODE <= 9 && t >= 14 && t < 18) *reinterpret_cast<f32x4*>(wdst + 512 * (t - 14)) = td[t - 14];
             if constexpr (MODE >= 6 && MODE <= 7 && t >= 18 && t < 22) *reinterpret_cast<f32x4*>(wdst + 512 * (t - 18) + 64) = rg[2 + t - 18];
             if constexpr (MODE == 7 && t >= 22 && t < 26) rg[2 + t - 22] = *reinterpret_cast<const f32x4*>(gc + 4096 + 2048 * (t - 22));
             if constexpr (MODE == 9 && t == 25) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");       // the DMA of the previous step has landed
             if constexpr (MODE == 9 && t >= 27 && t < 31)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gc + 4096 + 2048 * (t - 27)),
                                                  (__attribute__((address_space(3))) void*)(smem + 24576 + 2048 + (wave * 64 + 512 * (t - 27)) * 4), 16, 0, 0);
+            if constexpr (MODE == 10) *reinterpret_cast<float*>(wdst + 2048 * (t & 3) + (t >> 2) * 4 + (lane & 3)) = td[t & 7][t & 3];
+            if constexpr ((MODE == 11 || MODE == 12) && (t & 3) == 1) *reinterpret_cast<f32x4*>(wdst + 512 * (t >> 2)) = td[t >> 2];
+            if constexpr (MODE == 12) {
+                td[t & 7][t & 3] += tsrc[1024 + t * 64 + lane];
+                if constexpr (t < 4) td[t][3 - t] += tsrc[3072 + t * 64 + lane];
+            }
             if constexpr (MODE >= 1 && e == 0) {
                 fa[(xi + 1) & 1] = *reinterpret_cast<const f32x4*>(Vc + ((xi + 1) & 7) * 512);
                 fb[(xi + 1) & 1] = *reinterpret_cast<const f32x4*>(Uc + ((xi + 1) & 7) * 512);
@@ -131,5 +139,8 @@ int main() {
     run<7>("+ 6 global_load_dwordx4 per wave");
     run<8>("6 writes + 2 loads (U path dropped)");
     run<9>("6 writes + 2 loads + U by LDS-DMA");
+    run<10>("VALU + 32 ds_write_b32 per wave");
+    run<11>("VALU + 8 ds_write_b128 per wave");
+    run<12>("VALU + 8 ds_write_b128 + 36 ds_read_b32");
     return 0;
 }

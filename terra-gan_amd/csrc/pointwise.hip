@@ -106,8 +106,12 @@ __global__ __launch_bounds__(256) void colreduce4_kernel(F f, int64_t rows, int 
         for (int i = 0; i < NQ; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) q[i][e] = 0.f;
-        if (rl < rlanes && c0 < C)
+        if (rl < rlanes && c0 < C) {
+            // four rows per trip: their loads are independent of the running sums, so the compiler issues them together --
+            // a rolled loop keeps one or two 16-byte loads per thread in flight, far too few bytes per CU for the HBM latency
+#pragma unroll 4
             for (int64_t r = r0 + rl; r < r1; r += rlanes) f.quad(r, c0, q);
+        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NQ; ++i)

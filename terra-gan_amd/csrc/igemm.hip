@@ -2022,11 +2022,15 @@ extern "C" size_t tg_conv_wgrad_ws_bytes(const TgConv* g) {
         if (wf > slabs) slabs = wf;
         wf = align_up(wino22_wgrad_ws_floats(g), 64);
         if (wf > slabs) slabs = wf;
+        wf = align_up(wino16_wgrad_ws_floats(g), 64);
+        if (wf > slabs) slabs = wf;
     }
     if (s2d_ok(g)) {
         const TgConv g2 = s2d_geom(g);
         size_t wf = s2d_x_floats(g) + s2d_w_floats(g) + align_up(wino_wgrad_ws_floats(&g2), 64);
         if (wino_wgrad_ok(&g2, nullptr) && wf > slabs) slabs = wf;
+        wf = s2d_x_floats(g) + s2d_w_floats(g) + align_up(wino16_wgrad_ws_floats(&g2), 64);
+        if (wino16_wgrad_ok(&g2, nullptr) && wf > slabs) slabs = wf;
     }
     WgradParams sp = {};
     sp.C = g->Cin; sp.Cout = g->Cout; sp.k = g->k; sp.Mpix = g->B * g->Ho * g->Wo;
@@ -2068,7 +2072,8 @@ extern "C" int tg_conv_wgrad(const TgConv* g, const float* x, const float* in_ma
     }
     if (s2d_ok(g)) {
         const TgConv g2 = s2d_geom(g);
-        if (wino_wgrad_ok(&g2, nullptr)) {
+        const bool w16 = wino16_wgrad_ok(&g2, nullptr);
+        if (w16 || wino_wgrad_ok(&g2, nullptr)) {
             // 5x5 stride 2: Winograd wgrad over the (masked) space-to-depth input, then gather the 25 live taps
             float* x2 = ws;
             float* dw2 = ws + s2d_x_floats(g);
@@ -2081,19 +2086,29 @@ extern "C" int tg_conv_wgrad(const TgConv* g, const float* x, const float* in_ma
             p2.Ktot = 9 * g2.Cin;
             {
                 AlgScale sc(25.0 / 36.0);
-                rc = launch_wino_wgrad(&g2, p2, dw2, wsr, s);
+                rc = w16 ? launch_wino16_wgrad(&g2, p2, dw2, wsr, s) : launch_wino_wgrad(&g2, p2, dw2, wsr, s);
             }
             if (rc) return rc;
             hipLaunchKernelGGL(w5x5_s2d_kernel, dim3(ew_grid((int64_t)g->Cout * 25 * g->Cin, 256)), dim3(256), 0, s, dw2, dw, g->Cout,
                                g->Cin, 0);
             TG_CHECK_LAUNCH("w5x5_s2d_kernel");
             if (db) {
-                float* ws2 = wsr + align_up(wino_wgrad_ws_floats(&g2), 64);
+                float* ws2 = wsr + align_up(w16 ? wino16_wgrad_ws_floats(&g2) : wino_wgrad_ws_floats(&g2), 64);
                 rc = tg_colsum_launch(dy, (int64_t)p.Mpix, g->Cout, db, ws2, s);
                 if (rc) return rc;
             }
             return TG_OK;
         }
+    }
+    if (wino16_wgrad_ok(g, in_mask)) {        // bf16 mode: the same with bf16 MFMA operands (wino16.inc)
+        rc = launch_wino16_wgrad(g, p, dw, ws, s);
+        if (rc) return rc;
+        if (db) {
+            float* ws2 = ws + align_up(wino16_wgrad_ws_floats(g), 64);
+            rc = tg_colsum_launch(dy, (int64_t)p.Mpix, g->Cout, db, ws2, s);
+            if (rc) return rc;
+        }
+        return TG_OK;
     }
     if (wino_wgrad_ok(g, in_mask)) {          // stride-1 3x3, 64-multiples of channels: Winograd F(3x3,2x2)
         rc = launch_wino_wgrad(g, p, dw, ws, s);

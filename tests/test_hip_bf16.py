@@ -238,3 +238,49 @@ def test_wino16_gated_dgrad_and_determinism(dev):
     F.conv2d(xr, w.cpu().double(), None, 1, 1).backward(dy.cpu().permute(0, 3, 1, 2).double())
     ref = xr.grad.permute(0, 2, 3, 1) * (gate.cpu() > 0).double()
     assert float((a.cpu().double() - ref).norm() / ref.norm()) < 6e-3
+
+
+# ---- bf16-operand Winograd weight gradient (wino16_wgrad_kernel): stride-1 3x3, channel counts multiples of 64, >= 16 x 32
+# outputs, and the 5x5 stride-2 layers through space-to-depth
+W16_WGRAD_CASES = [   # B, H, W, Cin, Cout, k, stride, pad
+    (2, 32, 32, 64, 64, 3, 1, 1),
+    (1, 40, 48, 64, 128, 3, 1, 1),       # 48 = 1.5 strips of 32 pixels
+    (3, 17, 35, 128, 64, 3, 1, 1),       # odd sizes: half tiles at the right / bottom edge
+    (2, 20, 36, 64, 64, 3, 1, 0),        # pad 0
+    (4, 64, 64, 384, 64, 3, 1, 1),       # several Cin tiles (> 256: not the fp32 route), split-K over strips
+    (2, 64, 64, 64, 64, 5, 2, 2),        # 5x5 stride 2 -> 3x3 over the space-to-depth input
+]
+
+
+@pytest.mark.parametrize("case", W16_WGRAD_CASES)
+def test_wino16_wgrad(dev, case):
+    import csv
+    from tg_hip import lib as L, ops as O
+    B, H, W, Cin, Cout, k, s_, pad = case
+    g = torch.Generator().manual_seed(sum(case) + 7)
+    Ho, Wo = (H + 2 * pad - k) // s_ + 1, (W + 2 * pad - k) // s_ + 1
+    x = torch.randn(B, H, W, Cin, generator=g)
+    dy = torch.randn(B, Ho, Wo, Cout, generator=g)
+    w = torch.zeros(Cout, Cin, k, k).contiguous(memory_format=torch.channels_last).to(dev)
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Cout, Cin, k, k), dy.permute(0, 3, 1, 2).double(),
+                                      stride=s_, padding=pad)
+    lib = L.load()
+    O.set_precision("bf16")
+    for kind in (0, 1, 2, 3):
+        lib.tg_prof_summary(kind, None, None, None, None)
+    lib.tg_prof_enable(1)
+    dw, db = O.conv_wgrad(x.to(dev), dy.to(dev), w, k, s_, pad)
+    torch.cuda.synchronize()
+    lib.tg_prof_enable(0)
+    path = "/tmp/_w16g_%d.csv" % sum(case)
+    assert lib.tg_prof_dump(path.encode()) == 0
+    tags = [r["cfg"] for r in csv.DictReader(open(path))]
+    for kind in (0, 1, 2, 3):
+        lib.tg_prof_summary(kind, None, None, None, None)
+    assert "4116" in tags, tags                     # the bf16 Winograd wgrad kernel is the one that ran
+    e = dw.cpu().double() - ref
+    assert float(e.norm() / ref.norm()) < 6e-3, float(e.norm() / ref.norm())
+    assert torch.allclose(db.cpu().double(), dy.double().sum((0, 1, 2)), atol=1e-3, rtol=1e-5)
+    dw2, _ = O.conv_wgrad(x.to(dev), dy.to(dev), w, k, s_, pad)
+    assert torch.equal(dw, dw2)
+    O.set_precision("f32")

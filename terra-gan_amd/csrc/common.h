@@ -64,6 +64,17 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 // The wave bounces the tile through its own 32x36-float LDS scratch and comes back with 4 consecutive columns of one
 // row per lane: emit(row_in_tile, col_in_tile, f32x4) is called 4 times per lane -> 4 x 16-byte stores instead of
 // 16 x 4-byte ones.  A wave reads back only what it wrote itself (LDS ops of one wave complete in order): no barrier.
+// as tile_rows4, emit(t, row_in_tile, col_in_tile, f32x4) with the call index t = 0..3 (a constant after unrolling)
+template <class F>
+__device__ __forceinline__ void tile_rows4i(float* scratch, const f32x16& acc, int lane, F&& emit) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[r];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int rr = (lane >> 3) + 8 * t;
+        emit(t, rr, 4 * (lane & 7), *reinterpret_cast<const f32x4*>(scratch + rr * 36 + 4 * (lane & 7)));
+    }
+}
 template <class F>
 __device__ __forceinline__ void tile_rows4(float* scratch, const f32x16& acc, int lane, F&& emit) {
 #pragma unroll

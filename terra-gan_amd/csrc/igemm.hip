@@ -189,14 +189,15 @@ __device__ __forceinline__ int xcd_remap(int id, int total) {
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
 }
 
-__device__ __forceinline__ f32x4 epilogue4(const IGemmParams& p, f32x4 o, size_t pix, int nb) {
+// gv_pre: the gate values of these four outputs when the caller fetched them ahead of its stores (else they are loaded here)
+__device__ __forceinline__ f32x4 epilogue4(const IGemmParams& p, f32x4 o, size_t pix, int nb, const f32x4* gv_pre = nullptr) {
     const float rs = p.rowscale ? p.rowscale[pix] : 1.f;
     if (p.bias) o += *reinterpret_cast<const f32x4*>(p.bias + nb);
     o *= rs;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = apply_act(o[e], p.act, p.slope);
     if (p.gate) {
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(p.gate + pix * p.N + nb);
+        const f32x4 gv = gv_pre ? *gv_pre : *reinterpret_cast<const f32x4*>(p.gate + pix * p.N + nb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] *= gv[e] > 0.f ? 1.f : (p.gate_act == TG_ACT_LEAKY ? p.gate_slope : 0.f);
     }

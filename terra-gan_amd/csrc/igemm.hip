@@ -189,10 +189,13 @@ __device__ __forceinline__ int xcd_remap(int id, int total) {
     return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
 }
 
-// gv_pre: the gate values of these four outputs when the caller fetched them ahead of its stores (else they are loaded here)
-__device__ __forceinline__ f32x4 epilogue4(const IGemmParams& p, f32x4 o, size_t pix, int nb, const f32x4* gv_pre = nullptr) {
-    const float rs = p.rowscale ? p.rowscale[pix] : 1.f;
-    if (p.bias) o += *reinterpret_cast<const f32x4*>(p.bias + nb);
+// gv_pre / rs_pre / bias_pre: operands the caller fetched ahead of its stores (else they are loaded here).  On gfx9 vmcnt
+// counts stores as well as loads, so a load issued after a store waits for that store's write acknowledgement.
+__device__ __forceinline__ f32x4 epilogue4(const IGemmParams& p, f32x4 o, size_t pix, int nb, const f32x4* gv_pre = nullptr,
+                                           const float* rs_pre = nullptr, const f32x4* bias_pre = nullptr) {
+    const float rs = rs_pre ? *rs_pre : (p.rowscale ? p.rowscale[pix] : 1.f);
+    if (bias_pre) o += *bias_pre;
+    else if (p.bias) o += *reinterpret_cast<const f32x4*>(p.bias + nb);
     o *= rs;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = apply_act(o[e], p.act, p.slope);

@@ -176,6 +176,7 @@ W16_CASES = [   # B, H, W, Cin, Cout, k, stride, pad
     (1, 64, 48, 192, 64, 3, 1, 1),
     (2, 20, 20, 16, 64, 3, 1, 0),        # pad 0
     (2, 64, 64, 32, 64, 5, 2, 2),        # 5x5 stride 2 -> 3x3 over the space-to-depth input (enc2 / enc3 shape family)
+    (8, 128, 128, 64, 64, 3, 1, 1),      # 512 work items on 256 persistent workgroups: two items per workgroup
 ]
 
 

@@ -26,6 +26,9 @@ CASES = [
     (1, 64, 48, 192, 64, 1),
     (2, 20, 20, 16, 64, 0),       # pad 0: output 18x18
     (1, 18, 22, 16, 64, 2),       # pad 2: output 20x24
+    (8, 128, 128, 64, 64, 1),     # 512 work items on 256 workgroups: the staging pipeline runs across items (wino_pipe_kernel)
+    (4, 96, 96, 64, 128, 1),      # 288 items: some workgroups walk two (different N tiles of one patch), most one
+    (6, 80, 112, 24, 64, 1),      # 210 / 420 items of three 8-channel steps, ragged patches
 ]
 
 
@@ -203,6 +206,7 @@ W22_CASES = [
     (2, 32, 32, 256, 64),        # K = 1024 -> split-K slabs
     (1, 128, 128, 64, 128),      # the d2 geometry at batch 1
     (4, 32, 32, 128, 256),
+    (12, 128, 128, 64, 128),     # 384 (forward) / 1536 (dgrad) work items on 256 persistent workgroups
 ]
 
 

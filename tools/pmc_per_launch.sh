@@ -20,7 +20,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     for k in names:
-        per[(c, k)] = [float(r["Counter_Value"]) for r in rows if r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0] == k]
+        per[(c, k)] = [float(r["Counter_Value"]) for r in rows if r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].replace("wino_pipe_kernel", "wino_kernel") == k]
 launches = list(csv.DictReader(open(f"{root}/launches.csv")))
 w = csv.writer(open(out, "w"))
 w.writerow(["kernel", "tag", "M", "N", "K", "C", "splits", "ms", "alg_mb", "read_mb", "write_mb", "hbm_over_alg"])

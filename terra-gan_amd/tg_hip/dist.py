@@ -20,33 +20,47 @@ from .gradbuf import grad_buffers
 
 
 class Bucket:
-    __slots__ = ("params", "flat", "work")
+    __slots__ = ("params", "flat", "work", "owner")
 
-    def __init__(self, params, flat):
-        self.params, self.flat, self.work = params, flat, None
+    def __init__(self, params, flat, owner=None):
+        self.params, self.flat, self.work, self.owner = params, flat, None, owner
 
     def wait(self):
         if self.work is not None:
             self.work.wait()          # NCCL: makes the current stream wait; gloo: blocks the host
             self.work = None
+            if self.owner is not None:
+                self.owner._collective_done()
 
 
 class GradSync:
     def __init__(self, world_size=None, bucket_mb=25.0, group=None, cu_reserve=None):
         """cu_reserve: CUs the one-workgroup-per-CU Winograd launches leave free so that RCCL's kernels can run underneath
-        them (tg_set_cu_reserve).  Default: $TG_CU_RESERVE, else 8 (one per XCD) when world_size > 1.  UNMEASURED on a
-        multi-GPU node (the build box has one GPU): the value is a tunable, not a tuned constant."""
+        them (tg_set_cu_reserve).  Default: $TG_CU_RESERVE, else 8 (one per XCD) when world_size > 1.  The reserve is in
+        force only WHILE a collective launched here is in flight (from its launch to the wait that orders the compute
+        stream behind it): kernels enqueued outside that window use all CUs -- with 248 workgroups a layer of exactly 256
+        work items would take two rounds.  UNMEASURED on a multi-GPU node (the build box has one GPU): the value is a
+        tunable, not a tuned constant."""
         self.group = group
         self.world_size = world_size if world_size is not None else dist.get_world_size(group)
         import os
         if cu_reserve is None:
             cu_reserve = int(os.environ.get("TG_CU_RESERVE", "8" if self.world_size > 1 else "0"))
         self.cu_reserve = cu_reserve
-        if torch.cuda.is_available():
-            from . import lib as L
-            L.check(L.load().tg_set_cu_reserve(int(cu_reserve)), "tg_set_cu_reserve")
+        self._inflight = 0
+        self._set_reserve(0)
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self._plans = {}
+
+    def _set_reserve(self, r):
+        if torch.cuda.is_available():
+            from . import lib as L
+            L.check(L.load().tg_set_cu_reserve(int(r)), "tg_set_cu_reserve")
+
+    def _collective_done(self):
+        self._inflight -= 1
+        if self._inflight == 0:
+            self._set_reserve(0)
 
     @property
     def grad_scale(self):
@@ -89,8 +103,11 @@ class GradSync:
                 if p.grad.data_ptr() != view.data_ptr():      # gradient produced elsewhere (e.g. through autograd): pack it
                     view.copy_(p.grad)
                     p.grad = view
-            b = Bucket([p for p, _ in plist], flat[start:end])
+            b = Bucket([p for p, _ in plist], flat[start:end], self)
             if self.world_size > 1:
+                if self._inflight == 0:
+                    self._set_reserve(self.cu_reserve)
+                self._inflight += 1
                 b.work = self._all_reduce(b.flat)
             out.append(b)
         return out

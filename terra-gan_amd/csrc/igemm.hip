@@ -179,6 +179,24 @@ static int choose_splits(long tiles, int max_splits, int slots) {
 }
 
 
+// The same decision when the length of the K walk is known (`ksteps` steps in all): every workgroup walks
+// ceil(ksteps / splits) steps plus a fixed prologue / epilogue worth ~4 steps, `rounds` such walks follow each other, so the
+// launch costs rounds x (ceil(ksteps / splits) + 4) step times -- minimise that; ties go to fewer splits (fewer slabs to
+// write and reduce).  (choose_splits insists on filling a whole round first: 3 tiles x 85 splits = 255 workgroups on 256
+// CUs lost to 158 splits = 1.85 rounds, 7 % slower with twice the slabs.)
+static int choose_splits_k(long tiles, int max_splits, int slots, long ksteps) {
+    if (max_splits < 1) max_splits = 1;
+    int best = 1;
+    double best_cost = 1e300;
+    for (int sp = 1; sp <= max_splits; ++sp) {
+        const long blocks = tiles * sp;
+        const long rounds = (blocks + slots - 1) / slots;
+        const double cost = (double)rounds * ((double)((ksteps + sp - 1) / sp) + 4.0);
+        if (cost < best_cost * 0.995) { best_cost = cost; best = sp; }
+    }
+    return best;
+}
+
 // XCD-aware work remap (bijective): hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so
 // ids b and b+8 share an L2.  Map id -> work index such that each XCD gets a CONTIGUOUS range of work items;
 // callers order work items so that neighbours share operands (same pixels, different channel tiles).

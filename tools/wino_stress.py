@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised shape sweep of the Winograd / space-to-depth conv paths against PyTorch-CPU fp64 (run on an MI355X).
-    python tools/wino_stress.py [--n 40] [--seed 0]"""
+    python tools/wino_stress.py [--n 40] [--seed 0] [--big]
+--big: batches of 6-12 and up to 112 pixels a side, i.e. several work items per persistent workgroup (cross-item staging
+pipeline, interleaved walk), and every fourth case a 4x4 / stride-2 / pad-1 layer (the F(2x2,2x2) kernels)."""
 import argparse
 import os
 import random
@@ -19,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--big", action="store_true")
     args = ap.parse_args()
     L.load()
     dev = torch.device("cuda:0")
@@ -26,8 +29,14 @@ def main():
     worst = 0.0
     for it in range(args.n):
         s2d = it % 4 == 3
-        B = rnd.choice([1, 2, 3, 5])
-        if s2d:
+        B = rnd.choice([6, 8, 9, 12]) if args.big else rnd.choice([1, 2, 3, 5])
+        if args.big and s2d:
+            H, W = 2 * rnd.randint(24, 56), 2 * rnd.randint(24, 56)
+            Cin, Cout, k, s, p = rnd.choice([64, 128]), rnd.choice([64, 128]), 4, 2, 1
+        elif args.big:
+            H, W = rnd.randint(48, 112), rnd.randint(48, 112)
+            Cin, Cout, k, s, p = rnd.choice([16, 64, 64, 128]), rnd.choice([64, 128]), 3, 1, rnd.choice([0, 1, 1])
+        elif s2d:
             H, W = 2 * rnd.randint(32, 48), 2 * rnd.randint(32, 56)
             Cin, Cout, k, s, p = rnd.choice([16, 32, 64, 80]), rnd.choice([64, 128, 192]), 5, 2, 2
         else:
@@ -40,7 +49,7 @@ def main():
         w = torch.randn(Cout, Cin, k, k, generator=g) / (k * Cin ** 0.5)
         bias = torch.randn(Cout, generator=g) * 0.1
         mask = (torch.rand(B, H, W, generator=g) > 0.3).float()
-        use_mask = rnd.random() < 0.6
+        use_mask = rnd.random() < (0.3 if args.big else 0.6)
         wd = w.contiguous(memory_format=torch.channels_last).to(dev)
         m_d = mask.to(dev) if use_mask else None
         xm = (x * mask[..., None] if use_mask else x).permute(0, 3, 1, 2).double()

@@ -538,11 +538,8 @@ template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR, bool BF16 = fal
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
     igemm_body<WAVES_M, WAVES_N, WM, WN, SCALAR, BF16>(p, blockIdx.z);
 }
-// Up to 4 independent problems of one tile configuration in ONE launch (the parity classes of a stride-2 dgrad on a small
-// grid: four 17-us launches + four split-K epilogues per layer were pure launch latency): blockIdx.z = class * splits + split.
-struct IGemmMulti {
-    IGemmParams c[4];
-};
+// Up to 4 independent problems of one tile configuration in ONE launch (IGemmMulti; the parity classes of a stride-2 dgrad on a
+// small grid: four 17-us launches + four split-K epilogues per layer were pure launch latency): blockIdx.z = class * splits + split.
 template <int WAVES_M, int WAVES_N, int WM, int WN, bool BF16>
 __global__ __launch_bounds__(256, 2) void igemm_multi_kernel(const IGemmMulti pm, const int splits) {
     const int cls = blockIdx.z / splits;
@@ -1525,6 +1522,19 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, flo
     }
     if (mergeable && ncls > 0) {
         // the parity classes of a stride-2 dgrad go out as ONE patch-kernel launch when they qualify
+        if (smallconv_to1_multi_applies(cls, ncls)) {
+            // 64 -> 1 channel (D's first layer): the four classes in one launch read dy once from memory (they walk the same
+            // pixels at the same time) instead of four times
+            double fl = 0.0, by = 0.0;
+            for (int i = 0; i < ncls; ++i) {
+                cls[i].Ktot = cls[i].TH * cls[i].TW * cls[i].C;
+                fl += 2.0 * cls[i].M * (double)cls[i].N * cls[i].Ktot;
+                by += 4.0 * ((double)cls[i].M * cls[i].N + (double)cls[i].N * cls[i].Ktot);
+            }
+            by += 4.0 * (double)g->B * g->Ho * g->Wo * g->Cout;
+            ProfScope ps(s, 2, fl, by, cls[0].M * ncls, 1, cls[0].TH * cls[0].TW * cls[0].C, cls[0].C, 1, 2004);
+            return smallconv_to1_multi_launch(cls, ncls, s);
+        }
         if (ncls > 1 && !smallconv_fwd_applies(cls[0])) {
             IGemmParams tmp[4];
             for (int i = 0; i < ncls; ++i) tmp[i] = cls[i];

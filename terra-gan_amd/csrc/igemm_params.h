@@ -37,6 +37,11 @@ __device__ __forceinline__ float gate_factor(const IGemmParams& p, size_t idx) {
     return gv > 0.f ? 1.f : (p.gate_act == TG_ACT_LEAKY ? p.gate_slope : 0.f);
 }
 
+// Up to 4 independent problems in ONE launch (the parity classes of a stride-2 dgrad)
+struct IGemmMulti {
+    IGemmParams c[4];
+};
+
 struct WgradParams {
     const float* x;
     const float* amask;
@@ -51,6 +56,8 @@ struct WgradParams {
 // smallconv.hip: bandwidth-bound special cases that would waste >95% of an MFMA tile
 bool smallconv_fwd_applies(const IGemmParams& p);             // C == 1 -> N%64 == 0, or N == 1 <- C%64 == 0
 int smallconv_fwd_launch(const IGemmParams& p, hipStream_t s);
+bool smallconv_to1_multi_applies(const IGemmParams* cls, int ncls);   // 64 -> 1 channel, the four 2x2-tap classes of a 4x4 stride-2 dgrad
+int smallconv_to1_multi_launch(const IGemmParams* cls, int ncls, hipStream_t s);
 bool smallconv_wgrad_applies(const WgradParams& p);
 size_t smallconv_wgrad_ws_floats(const WgradParams& p);
 int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream_t s);

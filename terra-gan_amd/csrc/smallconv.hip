@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void c1mfma_kernel(const IGemmParams p, const 
 // pixels; the row base is wave-uniform (scalar ALU), the tap loops are unrolled and predicated, and the channel
 // reduction is a 4-step shuffle inside each 16-lane group.  Requires OW % 4 == 0.
 template <int TH_, int TW_>
-__global__ __launch_bounds__(256) void to1conv64_kernel(const IGemmParams p) {
+__device__ __forceinline__ void to1conv64_body(const IGemmParams& p) {
     constexpr int NT = TH_ * TW_;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = lane >> 4, cq = lane & 15;
@@ -293,6 +293,11 @@ __global__ __launch_bounds__(256) void to1conv64_kernel(const IGemmParams p) {
         }
     }
 }
+template <int TH_, int TW_>
+__global__ __launch_bounds__(256) void to1conv64_kernel(const IGemmParams p) { to1conv64_body<TH_, TW_>(p); }
+// the parity classes of a stride-2 dgrad as one launch: blockIdx.y = class; the classes walk the same source pixels at the
+// same time, so dy comes from memory once and from L2 three times
+__global__ __launch_bounds__(256) void to1conv64_multi22_kernel(const IGemmMulti pm) { to1conv64_body<2, 2>(pm.c[blockIdx.y]); }
 
 
 // ---- 64 channels -> 1 channel, 3x3 stride 1, through an LDS patch ------------------------------------------------------------
@@ -380,6 +385,25 @@ bool smallconv_fwd_applies(const IGemmParams& p) {
     if (p.C == 1 && p.N >= 64 && p.N % 64 == 0 && taps >= 1 && taps <= 64) return true;
     if (p.N == 1 && p.C == 64 && (p.OW % 4) == 0 && to1_cfg_ok(p.TH, p.TW)) return true;
     return false;
+}
+
+bool smallconv_to1_multi_applies(const IGemmParams* cls, int ncls) {
+    if (getenv("TG_NO_SMALLCONV") || getenv("TG_NO_TO1_MULTI") || ncls != 4) return false;
+    for (int i = 0; i < ncls; ++i) {
+        const IGemmParams& p = cls[i];
+        if (p.N != 1 || p.C != 64 || p.TH != 2 || p.TW != 2 || (p.OW & 3) || p.M != cls[0].M || p.OH != cls[0].OH || p.OW != cls[0].OW) return false;
+    }
+    return true;
+}
+int smallconv_to1_multi_launch(const IGemmParams* cls, int ncls, hipStream_t s) {
+    IGemmMulti pm = {};
+    for (int i = 0; i < ncls; ++i) pm.c[i] = cls[i];
+    int blocks = cdiv(cls[0].M / 4, 4 * 4);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(to1conv64_multi22_kernel, dim3(blocks, ncls), dim3(256), 0, s, pm);
+    TG_CHECK_LAUNCH("to1conv64_multi22_kernel");
+    return TG_OK;
 }
 
 #define TO1_CASE(TH_, TW_)                                                                           \

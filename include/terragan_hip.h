@@ -83,6 +83,14 @@ int tg_conv_dgrad_gated(const TgConv* g, const float* dy, const float* w, const 
 enum { TG_WPREP_FWD = 0, TG_WPREP_DGRAD = 1 };
 size_t tg_conv_wprep_bytes(const TgConv* g, int mode);
 int tg_conv_wprep(const TgConv* g, int mode, const float* w, float* wprep, tg_stream_t stream);
+/* Batched form: tg_conv_wprep_item writes a POD descriptor (tg_conv_wprep_item_bytes() bytes, HOST memory) of what
+ * tg_conv_wprep(g, mode, w, wprep) would launch and returns 1 -- or returns 0 when that preparation cannot be batched (it
+ * stays with tg_conv_wprep).  The caller copies the descriptors of all its layers into one DEVICE array once and has them
+ * executed by ONE launch per optimiser step: tg_conv_wprep_run(items_dev, n).  The descriptors hold the w / wprep pointers:
+ * they stay valid while those allocations live. */
+size_t tg_conv_wprep_item_bytes(void);
+int tg_conv_wprep_item(const TgConv* g, int mode, const float* w, float* wprep, void* item_out);
+int tg_conv_wprep_run(const void* items_dev, int n, tg_stream_t stream);
 int tg_conv_fwd_p(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* wprep,
                   const float* bias, const float* ratio, int act, float slope, float* y, float* ws,
                   size_t ws_bytes, tg_stream_t stream);

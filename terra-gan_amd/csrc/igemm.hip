@@ -1279,6 +1279,7 @@ static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, 
         float* x2 = ws;
         float* w2 = prep ? wprep : ws + s2d_x_floats(g);
         float* ws2 = ws ? ws + s2d_x_floats(g) + s2d_w_floats(g) : nullptr;
+        if (prep < 0 && g_wprep_capture) { g_wprep_captured = -1; return TG_OK; }      // two dependent passes: not batched
         if (prep <= 0) {
             hipLaunchKernelGGL(w5x5_s2d_kernel, dim3(ew_grid((int64_t)g->Cout * 36 * g->Cin, 256)), dim3(256), 0, s, w, w2, g->Cout, g->Cin, 1);
             TG_CHECK_LAUNCH("w5x5_s2d_kernel");
@@ -1409,6 +1410,32 @@ extern "C" int tg_conv_wprep(const TgConv* g, int mode, const float* w, float* w
         return conv_fwd_impl(g, nullptr, nullptr, w, wprep, -1, nullptr, nullptr, 0, 0.f, nullptr, nullptr, 0, stream);
     return conv_dgrad_impl(g, nullptr, w, wprep, -1, nullptr, nullptr, 0, nullptr, 0, 0.f, nullptr, 0, stream);
 }
+// Batched weight preparation.  tg_conv_wprep_item describes what tg_conv_wprep(g, mode, w, wprep) would launch as one POD
+// descriptor (returns 1), or returns 0 when this (geometry, mode) is not batchable (two dependent passes, bf16 / F(2x2,2x2)
+// transforms) or needs no preparation; the caller keeps the descriptors of all its layers in ONE device array and has them
+// executed by ONE launch per optimiser step (tg_conv_wprep_run) instead of one launch per layer and mode.
+extern "C" size_t tg_conv_wprep_item_bytes(void) { return sizeof(TgWprepItem); }
+extern "C" int tg_conv_wprep_item(const TgConv* g, int mode, const float* w, float* wprep, void* item_out) {
+    if (!g || !w || !wprep || !item_out || (mode != TG_WPREP_FWD && mode != TG_WPREP_DGRAD)) return 0;
+    if (tg_conv_wprep_bytes(g, mode) == 0) return 0;
+    TgWprepItem it = {};
+    g_wprep_capture = &it;
+    g_wprep_captured = 0;
+    int rc = mode == TG_WPREP_FWD ? conv_fwd_impl(g, nullptr, nullptr, w, wprep, -1, nullptr, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr)
+                                  : conv_dgrad_impl(g, nullptr, w, wprep, -1, nullptr, nullptr, 0, nullptr, 0, 0.f, nullptr, 0, nullptr);
+    g_wprep_capture = nullptr;
+    if (rc != TG_OK || g_wprep_captured != 1) return 0;
+    memcpy(item_out, &it, sizeof(it));
+    return 1;
+}
+extern "C" int tg_conv_wprep_run(const void* items_dev, int n, tg_stream_t stream) {
+    TG_REQUIRE(items_dev && n > 0, "tg_conv_wprep_run: bad arguments");
+    // 2048 x 256 threads per descriptor: the large layers need that many to cover the memory latency, the small ones' surplus
+    // blocks find nothing to do and leave
+    hipLaunchKernelGGL(wprep_multi_kernel, dim3(2048, n), dim3(256), 0, (hipStream_t)stream, static_cast<const TgWprepItem*>(items_dev));
+    TG_CHECK_LAUNCH("wprep_multi_kernel");
+    return TG_OK;
+}
 static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, float* wprep, int prep, const float* in_mask, float* dx,
                            int accumulate, const float* gate, int gate_act, float gate_slope, float* ws, size_t ws_bytes,
                            tg_stream_t stream) {
@@ -1425,6 +1452,7 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, flo
         float* dx2 = ws;
         float* w2 = prep ? wprep : ws + s2d_x_floats(g);
         float* wsr = ws ? ws + s2d_x_floats(g) + s2d_w_floats(g) : nullptr;
+        if (prep < 0 && g_wprep_capture) { g_wprep_captured = -1; return TG_OK; }
         if (prep <= 0) {
             hipLaunchKernelGGL(w5x5_s2d_kernel, dim3(ew_grid((int64_t)g->Cout * 36 * g->Cin, 256)), dim3(256), 0, s2, w, w2, g->Cout, g->Cin, 1);
             TG_CHECK_LAUNCH("w5x5_s2d_kernel");
@@ -1478,6 +1506,13 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, flo
         p.wino_u = wt;
         p.wino_ready = prep;
         return launch_wino22(g, p, 1, ws2_floats, s);
+    }
+    if (prep < 0 && g_wprep_capture) {
+        TgWprepItem it = {};
+        it.kind = 2; it.N = g->Cout; it.K = g->Cin; it.taps = taps; it.w = w; it.out = wt;
+        *g_wprep_capture = it;
+        g_wprep_captured = 1;
+        return TG_OK;
     }
     if (prep <= 0) {
         hipLaunchKernelGGL(transpose_w_kernel, dim3(ew_grid((int64_t)g->Cout * taps * g->Cin, 256)), dim3(256), 0, s, w, wt,

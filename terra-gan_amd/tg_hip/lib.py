@@ -34,6 +34,9 @@ SIGNATURES = {
     "tg_set_cu_reserve": (I, [I]),
     "tg_conv_wprep_bytes": (SZ, [CP, I]),
     "tg_conv_wprep": (I, [CP, I, P, P, P]),
+    "tg_conv_wprep_item_bytes": (SZ, []),
+    "tg_conv_wprep_item": (I, [CP, I, P, P, P]),
+    "tg_conv_wprep_run": (I, [P, I, P]),
     "tg_conv_fwd_p": (I, [CP, P, P, P, P, P, P, I, F, P, P, SZ, P]),
     "tg_conv_dgrad_p": (I, [CP, P, P, P, P, P, I, F, P, I, P, SZ, P]),
     "tg_conv_wgrad_ws_bytes": (SZ, [CP]),

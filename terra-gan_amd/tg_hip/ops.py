@@ -94,17 +94,48 @@ def conv_geom(x, cout, k, stride, pad):
 # ---- prepared weights (tg_conv_wprep): computed when a weight tensor is first used and again only after it changed --------
 WPREP_FWD, WPREP_DGRAD = 0, 1
 WPREP_CACHE = True            # False: every conv call prepares its weights in the workspace (the round-1 behaviour)
-_wprep = {}                   # (weight ptr, mode, geometry) -> [weakref(weight), version stamp, prepared buffer or None]
+WPREP_BATCH = True            # re-prepare all batchable entries of the updated weights in ONE launch right after the optimiser step
+_wprep = {}                   # (weight ptr, mode, geometry) -> [weakref(weight), version stamp, prepared buffer or None,
+                              #                                   batch descriptor (bytes) or False, used since the last batch]
 _wstamp = {}                  # weight ptr -> number of out-of-band updates (kernels writing through raw pointers)
+_wprep_tables = {}            # tuple of entry ids -> device array of their descriptors
 
 
 def weights_updated(params):
     """To be called by whoever rewrites parameters through raw pointers (hip_adam_step): torch's version counter does not
     see such writes, so the prepared-weight cache keeps its own stamp per storage."""
+    ptrs = set()
     for p in params:
         if p.dim() == 4:
             ptr = p.data_ptr()
             _wstamp[ptr] = _wstamp.get(ptr, 0) + 1
+            ptrs.add(ptr)
+    if WPREP_BATCH and WPREP_CACHE and ptrs:
+        _prepare_batch(ptrs)
+
+
+def _prepare_batch(ptrs):
+    """The prepared forms of the weights at `ptrs` that were used since the last batch, recomputed by ONE launch
+    (tg_conv_wprep_run over a cached device table of descriptors) instead of one launch per layer and mode at first use."""
+    ents = []
+    for key, e in _wprep.items():
+        if key[0] in ptrs and e[3] and e[4] and e[0]() is not None:
+            ents.append((key, e))
+    if not ents:
+        return
+    tkey = tuple(id(e) for _, e in ents)
+    table = _wprep_tables.get(tkey)
+    if table is None:
+        import numpy as np
+        raw = b"".join(e[3] for _, e in ents)
+        table = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(ents[0][1][2].device)
+        if len(_wprep_tables) > 16:
+            _wprep_tables.clear()
+        _wprep_tables[tkey] = table
+    L.check(_lib().tg_conv_wprep_run(C.c_void_p(table.data_ptr()), len(ents), _stream()), "tg_conv_wprep_run")
+    for key, e in ents:
+        e[1] = (e[0]()._version, _wstamp.get(key[0], 0))
+        e[4] = False
 
 
 def _prepared(w, wv, g, mode):
@@ -117,6 +148,7 @@ def _prepared(w, wv, g, mode):
     stamp = (w._version, _wstamp.get(ptr, 0))
     ent = _wprep.get(key)
     if ent is not None and ent[0]() is w and ent[1] == stamp:
+        ent[4] = True
         return ent[2]
     lib = _lib()
     if ent is None or ent[0]() is not w:            # first use (or the address was recycled for another tensor)
@@ -125,11 +157,17 @@ def _prepared(w, wv, g, mode):
         if len(_wprep) > 512:
             for k_ in [k_ for k_, e in _wprep.items() if e[0]() is None]:
                 del _wprep[k_]
-        ent = [weakref.ref(w), None, buf]
+        item = False
+        if buf is not None:
+            raw = C.create_string_buffer(lib.tg_conv_wprep_item_bytes())
+            if lib.tg_conv_wprep_item(C.byref(g), mode, _p(wv), _p(buf), raw):
+                item = raw.raw
+        ent = [weakref.ref(w), None, buf, item, True]
         _wprep[key] = ent
     if ent[2] is not None:
         L.check(lib.tg_conv_wprep(C.byref(g), mode, _p(wv), _p(ent[2]), _stream()), "tg_conv_wprep")
     ent[1] = stamp
+    ent[4] = True
     return ent[2]
 
 

@@ -1279,7 +1279,18 @@ static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, 
         float* x2 = ws;
         float* w2 = prep ? wprep : ws + s2d_x_floats(g);
         float* ws2 = ws ? ws + s2d_x_floats(g) + s2d_w_floats(g) : nullptr;
-        if (prep < 0 && g_wprep_capture) { g_wprep_captured = -1; return TG_OK; }      // two dependent passes: not batched
+        if (prep < 0 && g_wprep_capture) {
+            // batched preparation: the inner 3x3 problem describes its transform (on the regrouped weights), which is then
+            // re-pointed at the 5x5 weights themselves (kind 4 gathers them on the fly; the regrouped copy is not needed)
+            const int rc2 = conv_fwd_impl(&g2, nullptr, nullptr, w2, wprep + s2d_w_floats(g), -1, nullptr, nullptr, 0, 0.f, nullptr, nullptr,
+                                          0, stream);
+            if (rc2 == TG_OK && g_wprep_captured == 1 && g_wprep_capture->kind == 1) {
+                g_wprep_capture->kind = 4; g_wprep_capture->w = w; g_wprep_capture->taps = g->Cin;
+            } else {
+                g_wprep_captured = -1;
+            }
+            return rc2;
+        }
         if (prep <= 0) {
             hipLaunchKernelGGL(w5x5_s2d_kernel, dim3(ew_grid((int64_t)g->Cout * 36 * g->Cin, 256)), dim3(256), 0, s, w, w2, g->Cout, g->Cin, 1);
             TG_CHECK_LAUNCH("w5x5_s2d_kernel");
@@ -1452,7 +1463,15 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, flo
         float* dx2 = ws;
         float* w2 = prep ? wprep : ws + s2d_x_floats(g);
         float* wsr = ws ? ws + s2d_x_floats(g) + s2d_w_floats(g) : nullptr;
-        if (prep < 0 && g_wprep_capture) { g_wprep_captured = -1; return TG_OK; }
+        if (prep < 0 && g_wprep_capture) {
+            const int rc2 = conv_dgrad_impl(&g2, nullptr, w2, wprep + s2d_w_floats(g), -1, nullptr, nullptr, 0, nullptr, 0, 0.f, nullptr, 0, stream);
+            if (rc2 == TG_OK && g_wprep_captured == 1 && g_wprep_capture->kind == 1) {
+                g_wprep_capture->kind = 4; g_wprep_capture->w = w; g_wprep_capture->taps = g->Cin;
+            } else {
+                g_wprep_captured = -1;
+            }
+            return rc2;
+        }
         if (prep <= 0) {
             hipLaunchKernelGGL(w5x5_s2d_kernel, dim3(ew_grid((int64_t)g->Cout * 36 * g->Cin, 256)), dim3(256), 0, s2, w, w2, g->Cout, g->Cin, 1);
             TG_CHECK_LAUNCH("w5x5_s2d_kernel");

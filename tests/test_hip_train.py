@@ -583,3 +583,28 @@ def test_train_data_parallel_two_ranks(dev, tmp_path):
     assert res[0]["final_epoch"] == res[1]["final_epoch"] == 1
     assert res[0]["ckpt"] and not res[1]["ckpt"] and res[0]["tracked"] > 0 and res[1]["tracked"] == 0
     assert (tmp_path / "checkpoint_epoch_0.pth").exists()
+
+
+def test_batched_weight_preparation_matches_lazy(dev):
+    """The one-launch preparation of all updated weights after an optimiser step (tg_conv_wprep_run) and the per-layer lazy
+    preparation at first use run the same transforms: five train steps are bit-identical either way, and so are the weights."""
+    from mvp_gan.src.train import train_step
+    from oracle import terragan_oracle as Orc
+    from tg_hip import ops as O
+    runs = {}
+    for batch in (True, False):
+        O.WPREP_BATCH = batch
+        try:
+            G, D, crit, oG, oD = _build(dev, seed=3)
+            G.train(), D.train()
+            losses = []
+            for s in range(5):
+                real, mask = Orc.synth_batch(2, 128, 40 + s)
+                out = train_step(G, D, crit, oG, oD, real.to(dev), mask.to(dev))
+                losses.append([float(out[k]) for k in ("g_total", "d_loss")])
+            runs[batch] = (losses, [p.detach().clone() for p in list(G.parameters()) + list(D.parameters())], out["gen"].clone())
+        finally:
+            O.WPREP_BATCH = True
+    assert runs[True][0] == runs[False][0], (runs[True][0], runs[False][0])
+    assert torch.equal(runs[True][2], runs[False][2])
+    assert all(torch.equal(a, b) for a, b in zip(runs[True][1], runs[False][1]))

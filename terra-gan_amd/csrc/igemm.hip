@@ -1400,8 +1400,18 @@ static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, 
         p.w_raw = w; p.w_sn = (long)p.Kfull; p.w_sk = 1; p.w_stap = g->Cin;
         p.wino_u = prep ? wprep : ws;
         p.wino_ready = prep;
+        bool in_ws = !prep;
+        if (wino44_prepared_unusable(p)) {
+            // `wprep` holds the F(4x4,3x3) image (its layout follows the geometry alone) and this launch -- row scales, an input
+            // mask, or a batch whose output reaches 2 GB -- runs on wino_kernel: F(2x2,3x3) weights, transformed per call
+            TG_REQUIRE(ws_floats >= uf && aligned16(ws), "tg_conv_fwd: workspace too small to re-prepare the weights (%zu < %zu floats)",
+                       ws_floats, uf);
+            p.wino_u = ws;
+            p.wino_ready = 0;
+            in_ws = true;
+        }
         TG_REQUIRE(p.bf16 ? wino16_ok(p) : wino_ok(p), "tg_conv_fwd: internal: Winograd geometry predicate mismatch");
-        if (!prep) {
+        if (in_ws) {
             p.ws = ws + uf;
             ws_floats -= uf;
         }
@@ -1579,8 +1589,18 @@ static int conv_dgrad_impl(const TgConv* g, const float* dy, const float* w, flo
         p.wino_ready = prep;
         p.wino4 = g->precision == TG_PREC_F32_WINO4;
         if (wino44_ok(p)) return launch_wino44(p, s);
+        size_t avail = ws2_floats;
+        if (wino44_prepared_unusable(p)) {         // see conv_fwd_impl: F(4x4) image prepared, F(2x2) launch -> transform per call
+            const size_t uf = dgrad_wt_floats(g);
+            TG_REQUIRE(ws && aligned16(ws) && avail >= uf, "tg_conv_dgrad: workspace too small to re-prepare the weights (%zu < %zu floats)",
+                       avail, uf);
+            p.wino_u = ws;
+            p.wino_ready = 0;
+            p.ws = ws + uf;
+            avail -= uf;
+        }
         TG_REQUIRE(p.bf16 ? wino16_ok(p) : wino_ok(p), "tg_conv_dgrad: internal: Winograd geometry predicate mismatch");
-        return p.bf16 ? launch_wino16(p, ws2_floats, s) : launch_wino(p, ws2_floats, s);
+        return p.bf16 ? launch_wino16(p, avail, s) : launch_wino(p, avail, s);
     }
     if (wino22_dgrad_geom_ok(g)) {
         // 4x4 stride 2: the four parity classes as Winograd F(2x2,2x2) problems in one launch (wino22.inc)

@@ -71,6 +71,15 @@ class BucketLauncher:
         for i in range(len(self.plan)):
             if self.buckets[i] is None:
                 self._launch(i)
+        # A bucket that went out early was packed at ITS launch; a caller that pointed p.grad somewhere else afterwards
+        # (e.g. re-assigned the unreduced tensors an engine returned without persistent gradient buffers) would make the
+        # optimiser read unreduced gradients scaled by 1/world.  Refuse that pairing instead of training on it.
+        for plist, _s, _e in self.plan:
+            for p, off, k in plist:
+                if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
+                    raise RuntimeError(f"GradSync: the gradient of '{k}' no longer aliases the reduced bucket -- a backward that "
+                                       "reports gradients with ready(key, grad) must write them into tg_hip.gradbuf views "
+                                       "(or must not re-assign .grad after reporting them)")
         return self.launched
 
 
@@ -208,9 +217,10 @@ def broadcast_state(modules=(), optimizers=(), src=0, group=None):
         params = [p for g in opt.param_groups for p in g["params"]]
         if rank == src:
             sd = opt.state_dict()
+            # which entries are tensors is decided by KEY / rank, never by size: the moments of a 1-element parameter
+            # (G final.bias, D model.11.bias) are tensors like any other; only `step` (a 0-dim tensor) travels as a number
             meta = [{"param_groups": sd["param_groups"],
-                     "state": {i: {k: (float(v) if torch.is_tensor(v) and v.numel() == 1 else (None if torch.is_tensor(v) else v))
-                                   for k, v in st.items()} for i, st in sd["state"].items()}}]
+                     "state": {i: {k: _state_meta(k, v) for k, v in st.items()} for i, st in sd["state"].items()}}]
         else:
             meta = [None]
         dist.broadcast_object_list(meta, src=src, group=group)
@@ -238,6 +248,15 @@ def broadcast_state(modules=(), optimizers=(), src=0, group=None):
                     st[k] = torch.tensor(float(v), dtype=torch.float32)
                 else:
                     st[k] = v
+
+
+def _state_meta(key, v):
+    """What broadcast_state ships as an object for one optimiser-state entry: None = "a tensor, broadcast in place"."""
+    if not torch.is_tensor(v):
+        return v
+    if key == "step" or v.dim() == 0:
+        return float(v)
+    return None
 
 
 class ShardSampler(torch.utils.data.Sampler):

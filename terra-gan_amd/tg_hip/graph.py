@@ -46,12 +46,17 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         O.adam_scalar_arena = self.arena
         self.arena.active = True
+        O.wprep_capture_log = log = []
         try:
             with torch.cuda.graph(self.graph):
                 self.out = self._eager(self.real_s, self.mask_s)
         finally:
             self.arena.active = False
             O.adam_scalar_arena = None
+            O.wprep_capture_log = None
+        # what a replay changes behind the host-side prepared-weight cache (ops.graph_replayed)
+        self.wprep_keys = list(dict.fromkeys(log))
+        self.wptrs = sorted({p.data_ptr() for m in (self.G, self.D) for p in m.parameters() if p.dim() == 4 and p.requires_grad})
         # the capture executed hip_adam_step's HOST side (state["step"] += 1) without running a step on the device
         for opt in (self.oG, self.oD):
             for st in opt.state.values():
@@ -71,6 +76,7 @@ class GraphedTrainStep:
         self.arena.refresh(self.replays)
         self.graph.replay()
         self.replays += 1
+        O.graph_replayed(self.wptrs, self.wprep_keys)
         return self.out
 
     def flush(self):

@@ -105,6 +105,7 @@ _wprep = {}                   # (weight ptr, mode, geometry) -> [weakref(weight)
                               #                                   batch descriptor (bytes) or False, used since the last batch]
 _wstamp = {}                  # weight ptr -> number of out-of-band updates (kernels writing through raw pointers)
 _wprep_tables = {}            # (device, concatenated descriptor bytes) -> device array of those descriptors
+wprep_capture_log = None      # tg_hip.graph, while a step is captured: the keys whose batched preparation the graph replays
 
 
 def weights_updated(params):
@@ -146,6 +147,23 @@ def _prepare_batch(ptrs):
     for key, e in ents:
         e[1] = (e[0]()._version, _wstamp.get(key[0], 0))
         e[4] = False
+    if wprep_capture_log is not None:
+        wprep_capture_log.extend(key for key, _e in ents)
+
+
+def graph_replayed(weight_ptrs, refreshed_keys):
+    """A captured train step was replayed: the weights at `weight_ptrs` changed on the device behind the host's back.  Every
+    prepared form of them is stale from here on -- entries made eagerly for another geometry (validation / inference at
+    another size), and the non-batchable ones the graph re-prepares in its FORWARD, i.e. from the weights of before its
+    Adam -- except those in `refreshed_keys`, which the replayed tg_conv_wprep_run launch has just recomputed."""
+    for ptr in weight_ptrs:
+        _wstamp[ptr] = _wstamp.get(ptr, 0) + 1
+    for key in refreshed_keys:
+        e = _wprep.get(key)
+        if e is not None:
+            w = e[0]()
+            if w is not None:
+                e[1] = (w._version, _wstamp.get(key[0], 0))
 
 
 def _prepared(w, wv, g, mode):

@@ -155,7 +155,9 @@ def _bcast_worker(rank, world, port, q):
     sys.path.insert(0, os.path.join(root, "terra-gan_amd"))
     from tg_hip.dist import broadcast_state
     torch.manual_seed(rank)                           # different weights per rank
-    m = nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8))
+    # the last conv has a ONE-element bias, like G's final.bias (Conv2d(64,1)) and D's model.11.bias (Conv2d(512,1)): its Adam
+    # moments are 1-element tensors and must stay tensors (hip_adam_step takes their data_ptr)
+    m = nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8), nn.Conv2d(8, 1, 3))
     m[0].weight.data = m[0].weight.data.contiguous(memory_format=torch.channels_last)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     if rank == 0:                                     # only rank 0 has optimiser state (e.g. resumed from a checkpoint)
@@ -167,8 +169,18 @@ def _bcast_worker(rank, world, port, q):
     broadcast_state([m], [opt])
     assert m[0].weight.data_ptr() == ptr              # in place: gradient buffers / Adam tables stay valid
     st = opt.state[m[0].weight]
+    for p in m.parameters():
+        sp = opt.state[p]
+        assert torch.is_tensor(sp["step"]) and sp["step"].dim() == 0
+        for mk in ("exp_avg", "exp_avg_sq"):
+            assert torch.is_tensor(sp[mk]) and sp[mk].shape == p.shape, (mk, type(sp[mk]), tuple(p.shape))
+    for p in m.parameters():                          # and the state is usable: one more optimiser step on every rank
+        p.grad = torch.full_like(p, 0.5)
+    opt.step()
+    sb = opt.state[m[2].bias]
     q.put((rank, m[0].weight.detach().numpy().copy(), m[1].running_mean.numpy().copy(), float(st["step"]),
-           st["exp_avg"].numpy().copy()))
+           st["exp_avg"].numpy().copy(), sb["exp_avg"].numpy().copy(), sb["exp_avg_sq"].numpy().copy(),
+           m[2].bias.detach().numpy().copy()))
     dist.destroy_process_group()
 
 
@@ -185,4 +197,4 @@ def test_broadcast_state_two_ranks_gloo():
         assert p.exitcode == 0
     for a, b in zip(res[0], res[1]):
         assert (torch.as_tensor(a) == torch.as_tensor(b)).all()
-    assert res[1][2] == 1.0 and float(res[1][1][0]) == 0.25
+    assert res[1][2] == 2.0 and float(res[1][1][0]) == 0.25

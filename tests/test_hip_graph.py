@@ -68,3 +68,43 @@ def test_graphed_step_rejects_another_batch_shape(dev):
     real2, mask2 = (t.to(dev) for t in Orc.synth_batch(3, 128, 3))
     with pytest.raises(ValueError):
         step(real2, mask2)
+
+
+def test_eager_ops_between_replays_see_the_replayed_weights(dev):
+    """A replay rewrites G / D weights on the device; the host-side prepared-weight cache must not serve transforms of older
+    weights to eager work done between replays -- the reference validates between train steps (train.py:278-301: G.eval()
+    forward at the validation batch's size, D in train mode).  Compared with the same sequence run with the cache off."""
+    from oracle import terragan_oracle as Orc
+    from tg_hip import ops as O
+    from tg_hip.graph import GraphedTrainStep
+    from mvp_gan.src.train import validation_step
+    data = [tuple(t.to(dev) for t in Orc.synth_batch(2, 128, 70 + s)) for s in range(5)]
+    vdata = [tuple(t.to(dev) for t in Orc.synth_batch(3, 96, 90 + s)) for s in range(2)]          # another size AND batch
+    runs = {}
+    for cache in (True, False):
+        O.WPREP_CACHE = cache
+        try:
+            G, D, crit, oG, oD = _build(dev)
+            step = GraphedTrainStep(G, D, crit, oG, oD, warmup=1) if cache else None
+            from mvp_gan.src.train import train_step
+            rec = []
+            for i, (real, mask) in enumerate(data):
+                out = step(real, mask) if step is not None else train_step(G, D, crit, oG, oD, real, mask)
+                rec.append(float(out["g_total"]))
+                if i >= 1:                                   # from the first replay on: eager validation in between
+                    G.eval()
+                    for vr, vm in vdata:
+                        gt, dl = validation_step(G, D, crit, vr, vm)
+                        rec += [float(gt), float(dl)]
+                    with torch.no_grad():
+                        rec.append(float(D(data[0][0]).sum()))         # D forward at the TRAIN size: the non-batchable entries
+                    G.train()
+            torch.cuda.synchronize()
+            if step is not None:
+                assert step.replays == len(data) - 1
+            runs[cache] = (rec, {k: v.detach().clone() for m in (G, D) for k, v in m.state_dict().items()})
+        finally:
+            O.WPREP_CACHE = True
+    assert runs[True][0] == runs[False][0], (runs[True][0], runs[False][0])
+    for k, v in runs[False][1].items():
+        assert torch.equal(v, runs[True][1][k]), k

@@ -495,3 +495,49 @@ def test_wino44_fwd_dgrad(dev, case):
     assert (dxg.cpu().double() - refd * (xact > 0).double()).abs().max().item() <= tol, (case, "gate")
     # bitwise reproducible
     assert torch.equal(dx, O.conv_dgrad(dy.to(dev), w2d, (B, H, W, Ci2), 3, 1, pad, wino4=True))
+
+
+def test_wino44_prepared_weights_meet_a_launch_that_cannot_use_them(dev):
+    """The layout of a PREPARED weight buffer (F(4x4) or F(2x2) image) follows the geometry alone -- what the caller's cache key
+    holds -- never the launch: one cached weight then serves launches that run on wino44_kernel and launches that cannot
+    (row scales, an input mask, a batch whose output reaches 2 GB), in either order.  The latter transform F(2x2) weights
+    into their workspace (wino44_prepared_unusable, csrc/wino44.inc)."""
+    from tg_hip import ops as O
+    B, H, W, Cin, Cout = 2, 32, 64, 64, 128
+    g = torch.Generator().manual_seed(4402)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    mask = (torch.rand(B, H, W, generator=g) > 0.3).float()
+    _, ratio = O.mask_update(mask.to(dev), 3, 1, 1)
+    ref_plain = _ref_conv(x, w, bias, 1, None, None, None)
+    ref_pc = _ref_conv(x, w, bias, 1, mask, ratio.cpu(), None)
+    tol = lambda r: 8e-6 * max(1.0, r.abs().max().item()) + 1e-5
+    dy = torch.randn(B, H, W, Cout, generator=g)
+    refd = F.conv_transpose2d(dy.permute(0, 3, 1, 2).double(), w.double(), None, 1, 1).permute(0, 2, 3, 1)
+    for order in ("plain_first", "masked_first"):
+        wd = w.contiguous(memory_format=torch.channels_last).to(dev)      # a fresh tensor: a fresh cache entry
+        calls = [("plain", None, None, ref_plain), ("pc", mask.to(dev), ratio, ref_pc)]
+        for name, m, r, ref in (calls if order == "plain_first" else calls[::-1]) * 2:
+            y = O.conv_fwd(x.to(dev), wd, bias.to(dev), 3, 1, 1, in_mask=m, ratio=r, wino4=True)
+            err = (y.cpu().double() - ref).abs().max().item()
+            assert err <= tol(ref), (order, name, err)
+        dcalls = [("plain", None, refd), ("masked", mask.to(dev), refd * mask[..., None].double())]
+        for name, m, ref in (dcalls if order == "plain_first" else dcalls[::-1]) * 2:
+            dx = O.conv_dgrad(dy.to(dev), wd, (B, H, W, Cin), 3, 1, 1, in_mask=m, wino4=True)
+            err = (dx.cpu().double() - ref).abs().max().item()
+            assert err <= tol(ref), (order, "dgrad", name, err)
+    # the batch-size limit: 128 x 128 x 128 channels, B = 4 (wino44_kernel) and B = 256 (2 GB of output: wino_kernel) on ONE weight
+    g2 = torch.Generator().manual_seed(4403)
+    w2 = (torch.randn(128, 128, 3, 3, generator=g2) / 34.0).contiguous(memory_format=torch.channels_last).to(dev)
+    b2 = (torch.randn(128, generator=g2) * 0.1).to(dev)
+    xs = torch.randn(4, 128, 128, 128, generator=g2).to(dev)
+    ys = O.conv_fwd(xs, w2, b2, 3, 1, 1, wino4=True)
+    xb = xs.repeat(64, 1, 1, 1)
+    yb = O.conv_fwd(xb, w2, b2, 3, 1, 1, wino4=True)
+    assert yb.numel() * 4 >= 1 << 31
+    ys2 = O.conv_fwd(xs, w2, b2, 3, 1, 1, wino4=True)
+    assert torch.equal(ys, ys2)
+    for i in (0, 17, 63):
+        d = (yb[4 * i:4 * i + 4] - ys).abs().max().item()
+        assert d <= 2e-5 * max(1.0, ys.abs().max().item()), (i, d)

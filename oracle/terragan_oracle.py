@@ -197,20 +197,30 @@ def decode_step(up: Tensor, up_mask: Tensor, skip: Tensor, skip_mask: Tensor, p:
     return pconv(torch.cat([up, skip], 1), torch.maximum(up_mask, skip_mask), p, name, training)
 
 
-def generator_forward(p: Params, x: Tensor, mask: Tensor, training: bool = True) -> Tensor:
-    """PConvUNet.forward -- generator.py:31-64 (x is the already-masked image)."""
+def generator_forward(p: Params, x: Tensor, mask: Tensor, training: bool = True,
+                      taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """PConvUNet.forward -- generator.py:31-64 (x is the already-masked image).
+    `taps` (tests only): collects every layer's output activation (graph tensors: their gradients are the
+    activation gradients of the backward chain, tests/golden/make_golden.py steps_chain)."""
     e, m = [x], [mask]
     for i in range(1, 8):
         a, b = pconv(e[-1], m[-1], p, f"enc{i}", training)
+        if taps is not None:
+            taps[f"enc{i}"] = a
         e.append(a)
         m.append(b)
     d, dm = e[7], m[7]
     for lvl, name in zip(range(6, 0, -1), ["dec7", "dec6", "dec5", "dec4", "dec3", "dec2"]):
         d, dm = decode_step(d, dm, e[lvl], m[lvl], p, name, training)
+        if taps is not None:
+            taps[name] = d
     up = pad_to_match(F.interpolate(d, scale_factor=2, mode="bilinear", align_corners=False), x)
     upm = pad_to_match(F.interpolate(dm, scale_factor=2, mode="nearest"), mask)
     d0, _ = pconv(up, torch.maximum(upm, mask), p, "dec1", training)
-    out = torch.sigmoid(F.conv2d(d0, p["final.weight"], p["final.bias"], 1, 1))
+    logits = F.conv2d(d0, p["final.weight"], p["final.bias"], 1, 1)
+    if taps is not None:
+        taps["dec1"], taps["final"] = d0, logits
+    out = torch.sigmoid(logits)
     return out * (1 - mask) + x * mask
 
 

@@ -55,6 +55,10 @@ def _vgg_wino4(w, B, H, W, cout):
     return VGG_WINO4 and max(w.shape[0], w.shape[1]) >= VGG_WINO4_MINCH and items >= 256
 _side = {}
 SIDE_WGRAD = os.environ.get("TG_SIDE_STREAM") == "1"
+# Diagnostics (tests/test_hip_backward_chain.py, tools/backward_chain.py): PROBE(kind, name, tensor) is called with every
+# generator layer's output activation (kind "fwd") and with the gradient entering every layer's backward ("bwd", BEFORE the
+# layer consumes it in place).  None in production: one attribute test per layer.
+PROBE = None
 
 
 def _side_stream():
@@ -100,6 +104,8 @@ def _pconv_fwd(P, name, k, s, p, x, in_mask, ratio, training, premasked=False):
     else:
         mean, rstd = O.bn_eval_stats(P[f"{name}.bn.running_mean"], P[f"{name}.bn.running_var"])
         a = O.bn_act_fwd(y, mean, rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU)
+    if PROBE is not None:
+        PROBE("fwd", name, a)
     return a, NS(name=name, k=k, s=s, p=p, x=x, in_mask=in_mask, ratio=ratio, y=y, mean=mean, rstd=rstd,
                  premasked=premasked)
 
@@ -116,6 +122,8 @@ def _pconv_bwd(P, c, da, grads, dx_out=None, want_dx=True, gbuf=None, on_ready=N
     """da: grad w.r.t. the layer's ReLU output (consumed in place).  Returns dx (or None).
     gbuf: {state-dict key: preallocated gradient tensor} (tg_hip.gradbuf) -- written in place when given."""
     name = c.name
+    if PROBE is not None:
+        PROBE("bwd", name, da)
     outs = (gbuf[f"{name}.bn.weight"], gbuf[f"{name}.bn.bias"], gbuf[f"{name}.input_conv.bias"]) if gbuf is not None else None
     dyr, dgamma, dbeta, db = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU,
                                           ratio=c.ratio, outs=outs)
@@ -170,6 +178,9 @@ def generator_forward(P, x, mask, training=True, checkpoint=False):
     O.tag("final.fwd")
     logits = O.conv_fwd(d, P["final.weight"], P["final.bias"].detach(), 3, 1, 1)      # generator.py:29,56
     out = O.sigmoid_composite_fwd(logits.reshape(B, H, W), x, mask)                     # generator.py:57-62
+    if PROBE is not None:
+        PROBE("fwd", "final", logits)
+        PROBE("fwd", "gen", out)
     if checkpoint:
         for i in range(1, 7):
             enc_ctx[i].x_shape = tuple(enc_ctx[i].x.shape)
@@ -191,6 +202,9 @@ def generator_backward(P, ctx, dout, want_dx=False, gbuf=None, on_ready=None):
     ckpt = getattr(ctx, "checkpoint", False)
     dz, dx_comp = O.sigmoid_composite_bwd(dout, ctx.logits.reshape(B, H, W), ctx.mask, want_dx)
     dz = dz.reshape(B, H, W, 1)
+    if PROBE is not None:
+        PROBE("bwd", "gen", dout)
+        PROBE("bwd", "final", dz)
     d0 = _act_of(P, ctx.dec[6]) if ckpt else ctx.d0
     O.tag("final.dgrad")
     da = O.conv_dgrad(dz, P["final.weight"], tuple(d0.shape), 3, 1, 1)

@@ -519,6 +519,83 @@ def gen_steps_unc(cases=(("c1_256", 1, 256, 3, 1), ("b4_128", 4, 128, 3, 40)), w
     return out
 
 
+CHAIN_CASES = [("c2_b16_256", 16, 256, 500)]
+CHAIN_NSAMPLE = 2048
+
+
+def gen_steps_chain(cases=CHAIN_CASES, nsample=CHAIN_NSAMPLE):
+    """The generator's backward CHAIN at the headline size, layer by layer (round-3 verdict, item 1): the oracle evaluated in
+    fp64 -- every layer's output activation, the gradient entering every layer (d loss / d activation), the gradient of the
+    generated batch (what the loss stack + discriminator hand the generator) and every parameter gradient, each as a strided
+    sample (activations in NHWC order, parameters in logical OIHW order) -- next to the deviation of three fp32 evaluations
+    of the same arithmetic from it ON THE SAME SAMPLE (oneDNN convolutions = what the reference runs, ATen's native
+    convolutions, one thread).  A GPU test walks the chain from `final` back to `enc1` and reports where the HIP path's
+    deviation from fp64 leaves the spread of the CPU fp32 evaluations (tests/test_hip_backward_chain.py)."""
+    from oracle import terragan_oracle as Orc
+    out = {}
+
+    def sample_of(t, nhwc):
+        t = t.detach()
+        if nhwc and t.dim() == 4:
+            t = t.permute(0, 2, 3, 1)
+        t = t.reshape(-1)
+        stride = max(1, t.numel() // nsample)
+        return t[::stride][:nsample].double().clone(), stride
+
+    def run(dtype, b, size, seed0):
+        st = Orc.TrainState(0).to(dtype)
+        real, mask = synth_batch(b, size, seed0)
+        real, mask = real.to(dtype), mask.to(dtype)
+        gk = Orc.trainable(st.gp)
+        for k in gk:
+            st.gp[k].requires_grad_(True)
+        taps = {}
+        gen = Orc.generator_forward(st.gp, real * mask, mask, True, taps)
+        g_loss, _ = Orc.inpainting_loss(st.vp, gen, real, mask, *st.w)
+        g_adv = Orc.bce_logits(Orc.discriminator_forward(st.dp, gen, True), 1.0)
+        names = list(taps)
+        gs = torch.autograd.grad(g_loss + g_adv, [gen] + [taps[n] for n in names] + [st.gp[k] for k in gk])
+        res = {"bwd/gen": (gs[0], True), "fwd/gen": (gen, True)}
+        for n, g in zip(names, gs[1:1 + len(names)]):
+            res[f"fwd/{n}"] = (taps[n], True)
+            res[f"bwd/{n}"] = (g, True)
+        for k, g in zip(gk, gs[1 + len(names):]):
+            res[f"grad/{k}"] = (g, False)
+        outd = {}
+        for key, (t, nhwc) in res.items():
+            smp, stride = sample_of(t, nhwc)
+            td = t.detach().double()
+            outd[key] = (smp, stride, float(td.abs().max()), float(td.pow(2).mean().sqrt()), t.numel())
+        return outd
+
+    for tag, b, size, seed0 in cases:
+        out[f"{tag}/cfg"] = np.array([b, size, seed0, nsample], dtype=np.int64)
+        r64 = run(torch.float64, b, size, seed0)
+        print(f"  {tag}: fp64 done", flush=True)
+        for key, (smp, stride, mx, rms, n) in r64.items():
+            out[f"{tag}/{key}/ref"] = smp.numpy()
+            out[f"{tag}/{key}/stride"] = np.int64(stride)
+            out[f"{tag}/{key}/scale"] = np.array([mx, rms, n], dtype=np.float64)      # max|ref|, rms(ref) over the FULL tensor, numel
+        variants = [("onednn", True, None), ("native", False, None), ("onethread", True, 1)]
+        out[f"{tag}/variants"] = np.array([v[0] for v in variants])
+        devs = {key: [] for key in r64}
+        for name, mkldnn_on, nthreads in variants:
+            old_threads = torch.get_num_threads()
+            if nthreads:
+                torch.set_num_threads(nthreads)
+            with torch.backends.mkldnn.flags(enabled=mkldnn_on):
+                r32 = run(torch.float32, b, size, seed0)
+            torch.set_num_threads(old_threads)
+            for key in r64:
+                d = r32[key][0] - r64[key][0]
+                devs[key].append([float(d.abs().max()), float(d.pow(2).mean().sqrt())])
+            print(f"  {tag}: fp32 variant {name} done", flush=True)
+        for key in r64:
+            out[f"{tag}/{key}/dev"] = np.array(devs[key], dtype=np.float64)          # [variant][max|d|, rms(d)] on the sample
+    return out
+
+
+
 def gen_models_unc():
     """fp32-vs-fp64 deviation of the `models` fixtures' quantities (whole-generator forward/backward at tiny sizes, where
     BatchNorm runs over 2-3 values per channel at the bottleneck), from the oracle: [max|d|, sum|d|, ||d||_2, max|ref|] per
@@ -619,7 +696,8 @@ def main():
     only = sys.argv[1:]
     jobs = {"steps_unc": gen_steps_unc,           # oracle only: do not need the reference
             "steps_full_unc": lambda: gen_steps_unc(FULL_CASES, with_dp=False, alts=True),
-            "models_unc": gen_models_unc}
+            "models_unc": gen_models_unc,
+            "steps_chain": gen_steps_chain}
     if not only or any(n not in jobs for n in only):
         ref_pconv, ref_gen, ref_disc, ref_losses = _load_reference()
         jobs.update(_reference_jobs(ref_pconv, ref_gen, ref_disc, ref_losses))

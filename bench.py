@@ -332,6 +332,14 @@ def main():
                            "global_batch": args.batch * world, "tile": args.size,
                            "parallelism": f"dp{world}" if world > 1 else "single-gpu",
                            "launch": "hipGraph replay" if args.graph else "eager",
+                           # what the process group itself reports (not the arguments): proof of N ranks on the named transport
+                           "dist": ({"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                     "g_buckets": len(sync._plans["G"][1]) if "G" in sync._plans else None,
+                                     "d_buckets": len(sync._plans["D"][1]) if "D" in sync._plans else None,
+                                     "bucket_mb": round(sync.bucket_elems * 4 / (1 << 20), 1),
+                                     "exchange": "all-reduce(sum) of G and D gradient buckets, each launched when its last "
+                                                 "gradient is enqueued; Adam per bucket after its wait; 1/world in the Adam kernel"}
+                                    if (sync is not None and dist.is_initialized()) else None),
                            "vgg_weights": "deterministic stand-in (ImageNet weights not fetchable offline; same FLOPs)"},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)

@@ -283,6 +283,9 @@ int tg_lincomb(const float* x, float a, const float* y, float b, float* out, int
                tg_stream_t stream);
 /* out = a*b elementwise (masked_imgs = real_imgs * masks, train.py:181). */
 int tg_mul(const float* a, const float* b, float* out, int64_t n, tg_stream_t stream);
+/* out = a*b and a_copy = a from one read of a: masked_imgs (train.py:181) plus real_imgs placed behind the generated batch
+ * in the stacked [gen; real] buffer the loss trunk (losses.py:79-88) and the discriminator passes (train.py:202,211) read. */
+int tg_mul_keep(const float* a, const float* b, float* out, float* a_copy, int64_t n, tg_stream_t stream);
 /* Re-apply the BatchNorm running-stat momentum update from saved batch statistics
  * (mean, rstd as written by tg_bn_stats): used when a forward pass is provably identical to one
  * already computed (D(gen) and D(gen.detach()), train.py:202,212) and only its running-stat side

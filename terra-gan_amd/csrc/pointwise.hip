@@ -1546,6 +1546,23 @@ extern "C" int tg_mul(const float* a, const float* b, float* out, int64_t n, tg_
     return TG_OK;
 }
 
+// out = a*b and keep = a from ONE read of a: the train step needs real*mask (train.py:181) and, stacked behind the generated
+// batch, real itself (the loss trunk and the discriminator see [gen; real]) -- no separate copy, no concatenation
+__global__ __launch_bounds__(256) void mul_keep_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                       float* __restrict__ keep, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = a[i];
+        out[i] = v * b[i];
+        keep[i] = v;
+    }
+}
+extern "C" int tg_mul_keep(const float* a, const float* b, float* out, float* a_copy, int64_t n, tg_stream_t stream) {
+    TG_REQUIRE(a && b && out && a_copy && n > 0, "tg_mul_keep: bad arguments");
+    hipLaunchKernelGGL(mul_keep_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S(stream), a, b, out, a_copy, n);
+    TG_CHECK_LAUNCH("mul_keep_kernel");
+    return TG_OK;
+}
+
 __global__ __launch_bounds__(256) void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 double n, int C, float eps, float momentum,
                                                                 float* __restrict__ rm, float* __restrict__ rv,

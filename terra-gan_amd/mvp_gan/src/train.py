@@ -137,13 +137,16 @@ def _train_step(generator, discriminator, criterion, optimizer_G, optimizer_D, r
     GP, DP = generator._tensors(), discriminator._tensors()
     real, mask = as_bhw(real_imgs, "train_step"), as_bhw(masks, "train_step")
     B, H, W = real.shape
-    masked = O.mul(real, mask)                                               # train.py:181
+    # [gen; real] stacked along the batch: what the perceptual trunk (losses.py:79-88) and the grouped discriminator forward
+    # read.  real lands there from the pass that computes real*mask, gen is written there by the generator itself.
+    both = torch.empty((2 * B, H, W), dtype=torch.float32, device=real.device)
+    masked = O.mul(real, mask, keep=both[B:])                                # train.py:181
 
     # ---- generator ------------------------------------------------------------------------------
     optimizer_G.zero_grad()                                                  # set_to_none (App. A #12)
     gen, gctx = E.generator_forward(GP, masked, mask, generator.training,
-                                    checkpoint=getattr(generator, "activation_checkpointing", False))     # train.py:185
-    g_loss, _parts, dgen = criterion_forward(criterion, gen, real, mask, want_grad=True)   # train.py:188
+                                    checkpoint=getattr(generator, "activation_checkpointing", False), out=both[:B])     # train.py:185
+    g_loss, _parts, dgen = criterion_forward(criterion, gen, real, mask, want_grad=True, both=both)   # train.py:188
     # D(fake) of this step (train.py:202), D(real) and D(fake.detach()) of the discriminator step (train.py:211-212) see the
     # same discriminator weights, and D(real) depends on nothing the generator step produces: the two distinct passes are
     # stacked along the batch and run as ONE grouped forward (convolutions once over 2B images, BatchNorm statistics per
@@ -151,7 +154,7 @@ def _train_step(generator, discriminator, criterion, optimizer_G, optimizer_D, r
     # reference's order fake, real, fake.
     grouped = reuse_fake_forward and discriminator.training
     if grouped:
-        logits2, dctx2 = E.discriminator_forward(DP, torch.cat([gen, real]), True, groups=2, update_running=False)
+        logits2, dctx2 = E.discriminator_forward(DP, both, True, groups=2, update_running=False)
         E.discriminator_replay_running_stats(DP, dctx2, order=(0,))          # train.py:202
         fake_logits, real_logits = logits2[:B], logits2[B:]
         dctx_fake = E.discriminator_group(dctx2, 0)
@@ -182,12 +185,13 @@ def _train_step(generator, discriminator, criterion, optimizer_G, optimizer_D, r
     else:
         real_logits, dctx_real = E.discriminator_forward(DP, real, discriminator.training)     # train.py:211
         fake_logits, dctx_fake = E.discriminator_forward(DP, gen, discriminator.training)      # train.py:212
-    real_loss, dl_real = O.bce_logits(real_logits, 1.0, coef=0.5)            # train.py:215,217
-    fake_loss, dl_fake = O.bce_logits(fake_logits, 0.0, coef=0.5)            # train.py:216,217
+    dl2 = torch.empty_like(logits2) if grouped else None                     # [dl_fake; dl_real], the order of the grouped forward
+    real_loss, dl_real = O.bce_logits(real_logits, 1.0, coef=0.5, dz_out=dl2[B:] if grouped else None)     # train.py:215,217
+    fake_loss, dl_fake = O.bce_logits(fake_logits, 0.0, coef=0.5, dz_out=dl2[:B] if grouped else None)     # train.py:216,217
     d_loss = O.lincomb(real_loss, 0.5, fake_loss, 0.5)
     dl_ = grad_sync.begin(discriminator, "D") if grad_sync is not None else None
     if grouped:
-        dg_real, _ = E.discriminator_backward(DP, dctx2, torch.cat([dl_fake, dl_real]), want_wgrad=True,
+        dg_real, _ = E.discriminator_backward(DP, dctx2, dl2, want_wgrad=True,
                                               gbuf=grad_buffers(discriminator).views,
                                               on_ready=dl_.ready if dl_ is not None else None)      # train.py:218
     else:

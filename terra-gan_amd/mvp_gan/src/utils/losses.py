@@ -128,7 +128,7 @@ class _PixelLossFn(torch.autograd.Function):
         return dp.reshape(ctx.shape), None, None, None, None, None, None, None
 
 
-def criterion_forward(crit, pred, target, mask, want_grad, gscale=None, l1_weight=None, w_l1=1.0, scale=1.0):
+def criterion_forward(crit, pred, target, mask, want_grad, gscale=None, l1_weight=None, w_l1=1.0, scale=1.0, both=None):
     """Fused value(+gradient) of InpaintingLoss on [B][H][W] tensors.
     Returns (total 1-elem tensor, parts dict of 1-elem tensors, dpred or None).  `scale` multiplies
     the whole loss (HumanGuidedLoss's base_loss_weight)."""
@@ -140,9 +140,10 @@ def criterion_forward(crit, pred, target, mask, want_grad, gscale=None, l1_weigh
     if w_p > 0:
         V = crit._vgg_tensors()
         B = pred.shape[0]
-        both = torch.empty((2 * B,) + tuple(pred.shape[1:]), dtype=pred.dtype, device=pred.device)
-        both[:B].copy_(pred)            # device-to-device memcpy (plumbing)
-        both[B:].copy_(target)
+        if both is None:                # `both` = [pred; target] stacked along the batch, when the caller already holds it
+            both = torch.empty((2 * B,) + tuple(pred.shape[1:]), dtype=pred.dtype, device=pred.device)
+            both[:B].copy_(pred)        # device-to-device memcpy (plumbing)
+            both[B:].copy_(target)
         feats, vctx = E.vgg_forward(V, both, keep=want_grad)
         fp, ft = feats[:B], feats[B:]
         perc, dfeat = O.l1_mean(fp, ft, w_p * scale, gscale=gscale, want_grad=want_grad)

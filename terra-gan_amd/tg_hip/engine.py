@@ -147,8 +147,9 @@ def _pconv_bwd(P, c, da, grads, dx_out=None, want_dx=True, gbuf=None, on_ready=N
 # --------------------------------------------------------------------------------------------------
 # generator
 # --------------------------------------------------------------------------------------------------
-def generator_forward(P, x, mask, training=True, checkpoint=False):
-    """x (already masked image) and mask: [B][H][W].  Returns (out [B][H][W], ctx).
+def generator_forward(P, x, mask, training=True, checkpoint=False, out=None):
+    """x (already masked image) and mask: [B][H][W].  Returns (out [B][H][W], ctx).  `out`: preallocated destination of the
+    generated batch (train_step: the first half of the stacked [gen; real] buffer).
     checkpoint=True (activation checkpointing, BASELINE config 5): only the pre-BatchNorm conv outputs, the batch
     statistics and the (1-channel) masks are kept; the post-activation tensors and the decoder concat tensors --
     more than half of the footprint -- are dropped and recomputed in backward (one BN+ReLU pass and one
@@ -177,7 +178,7 @@ def generator_forward(P, x, mask, training=True, checkpoint=False):
         dec_ctx.append(c)
     O.tag("final.fwd")
     logits = O.conv_fwd(d, P["final.weight"], P["final.bias"].detach(), 3, 1, 1)      # generator.py:29,56
-    out = O.sigmoid_composite_fwd(logits.reshape(B, H, W), x, mask)                     # generator.py:57-62
+    out = O.sigmoid_composite_fwd(logits.reshape(B, H, W), x, mask, out=out)            # generator.py:57-62
     if PROBE is not None:
         PROBE("fwd", "final", logits)
         PROBE("fwd", "gen", out)

@@ -84,6 +84,7 @@ SIGNATURES = {
     "tg_axpby": (I, [P, F, F, P, I64, P]),
     "tg_lincomb": (I, [P, F, P, F, P, I64, P]),
     "tg_mul": (I, [P, P, P, I64, P]),
+    "tg_mul_keep": (I, [P, P, P, P, I64, P]),
     "tg_bn_running_update": (I, [P, P, I64, I, F, F, P, P, P, P]),
     "tg_quality_metrics_ws_bytes": (SZ, [I64, I, I]),
     "tg_quality_metrics": (I, [P, P, P, I64, I, I, P, P, SZ, P]),

@@ -475,8 +475,11 @@ def upcat_bwd(dout, h, w, Cu, want_skip=True):
     return dup, dskip
 
 
-def sigmoid_composite_fwd(logits, x, mask):
-    out = torch.empty_like(x)
+def sigmoid_composite_fwd(logits, x, mask, out=None):
+    _chk(out, "out")
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.shape == x.shape
     L.check(_lib().tg_sigmoid_composite_fwd(_p(logits), _p(x), _p(mask), x.numel(), _p(out), _stream()), "tg_sigmoid_composite_fwd")
     return out
 
@@ -532,10 +535,13 @@ def l1_mean(a, b, coef=1.0, gscale=None, want_grad=True):
     return out, da
 
 
-def bce_logits(z, target, coef=1.0, gscale=None, want_grad=True):
-    _chk(z, "z")
+def bce_logits(z, target, coef=1.0, gscale=None, want_grad=True, dz_out=None):
+    """dz_out: preallocated destination of the gradient (a slice of a stacked buffer), same shape as z."""
+    _chk(z, "z"); _chk(dz_out, "dz_out")
     out = empty(1, like=z)
-    dz = torch.empty_like(z) if want_grad else None
+    if dz_out is not None:
+        assert want_grad and dz_out.shape == z.shape
+    dz = (dz_out if dz_out is not None else torch.empty_like(z)) if want_grad else None
     lib = _lib()
     ws = workspace(lib.tg_reduce_ws_bytes(z.numel()))
     L.check(lib.tg_bce_logits(_p(z), z.numel(), target, coef, _p(gscale), _p(out), _p(dz), _p(ws), ws.numel() * 4, _stream()),
@@ -674,10 +680,15 @@ def lincomb(x, a, y, b):
     return out
 
 
-def mul(a, b):
-    _chk(a, "a"); _chk(b, "b")
+def mul(a, b, keep=None):
+    """a*b; keep (optional, same shape, contiguous): also receives a copy of `a` from the same pass (tg_mul_keep)."""
+    _chk(a, "a"); _chk(b, "b"); _chk(keep, "keep")
     out = torch.empty_like(a)
-    L.check(_lib().tg_mul(_p(a), _p(b), _p(out), a.numel(), _stream()), "tg_mul")
+    if keep is not None:
+        assert keep.numel() == a.numel()
+        L.check(_lib().tg_mul_keep(_p(a), _p(b), _p(out), _p(keep), a.numel(), _stream()), "tg_mul_keep")
+    else:
+        L.check(_lib().tg_mul(_p(a), _p(b), _p(out), a.numel(), _stream()), "tg_mul")
     return out
 
 

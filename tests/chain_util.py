@@ -18,7 +18,7 @@ def layer_params(name):
     return [f"{name}.input_conv.weight", f"{name}.input_conv.bias", f"{name}.bn.weight", f"{name}.bn.bias"]
 
 
-def measure_chain(dev, tag="c2_b16_256", seed=0):
+def measure_chain(dev, tag="c2_b16_256", seed=0, fixture="steps_chain"):
     """One generator forward + backward of the train step on the HIP path with engine probes -> rows
     {key: dict(hip_max, hip_rms, cpu_max, cpu_rms, ratio_max, ratio_rms, ref_max, ref_rms, stated)} where
     *_max / *_rms are the deviation from the fp64 sample, cpu_* the LARGEST over the three CPU fp32 evaluations and
@@ -28,8 +28,10 @@ def measure_chain(dev, tag="c2_b16_256", seed=0):
     from mvp_gan.src.utils.losses import InpaintingLoss
     from oracle import terragan_oracle as Orc
     from tg_hip import engine as E
-    gold = GU.load("steps_chain")
-    b, size, seed0, _ns = [int(v) for v in gold[f"{tag}/cfg"]]
+    gold = GU.load(fixture)
+    cfg = [int(v) for v in gold[f"{tag}/cfg"]]
+    b, size, seed0, _ns = cfg[:4]
+    gy_mode = len(cfg) > 4 and cfg[4] == 1        # a seeded smooth upstream gradient instead of the loss stack's (make_golden.py)
     torch.manual_seed(seed)
     G, D = PConvUNet(), Discriminator()
     crit = InpaintingLoss(0.1, 0.1, device=torch.device("cpu"))
@@ -47,16 +49,25 @@ def measure_chain(dev, tag="c2_b16_256", seed=0):
 
     E.PROBE = probe
     try:
-        train_step(G, D, crit, oG, oD, real.to(dev), mask.to(dev))
+        if gy_mode:
+            from tg_hip import ops as O
+            GP = G._tensors()
+            rb, mb = real.to(dev).reshape(b, size, size), mask.to(dev).reshape(b, size, size)
+            gen, gctx = E.generator_forward(GP, O.mul(rb, mb), mb, True)
+            gy = (torch.randn(b, 1, size, size, generator=torch.Generator().manual_seed(5)) / (b * size * size)).to(dev)
+            grads, _ = E.generator_backward(GP, gctx, gy.reshape(b, size, size).contiguous())
+        else:
+            train_step(G, D, crit, oG, oD, real.to(dev), mask.to(dev))
+            grads = {k: p_.grad for k, p_ in G.named_parameters() if p_.requires_grad}
         torch.cuda.synchronize()
     finally:
         E.PROBE = None
-    for k, p_ in G.named_parameters():
+    for k, g_ in grads.items():
         key = f"{tag}/grad/{k}"
-        if p_.requires_grad and key + "/ref" in gold:
+        if key + "/ref" in gold:
             stride = int(gold[key + "/stride"])
             n = gold[key + "/ref"].shape[0]
-            got[key] = p_.grad.detach().flatten()[::stride][:n].double().cpu()      # logical OIHW order
+            got[key] = g_.detach().flatten()[::stride][:n].double().cpu()           # logical OIHW order
     rows = {}
     for key, mine in got.items():
         ref = torch.from_numpy(gold[key + "/ref"]).double()

@@ -519,11 +519,23 @@ def gen_steps_unc(cases=(("c1_256", 1, 256, 3, 1), ("b4_128", 4, 128, 3, 40)), w
     return out
 
 
+# (tag, batch, size, data seed[, mode]): mode "step" = the train step's generator loss (train.py:188-204) drives the backward;
+# "gy" = a seeded smooth upstream gradient instead (sum(gen * gy), gy ~ N(0,1)/numel): the SAME forward and backward chain of
+# the generator without the loss stack's discontinuities (|p - t| and LeakyReLU / ReLU / max-pool gates of D and the VGG
+# trunk: where p ~ t to rounding a single boundary-loss pixel flips a gradient of 0.5 / sum(band) -- any two fp32 evaluations
+# may disagree on it, the reference's own CPU evaluations included)
 CHAIN_CASES = [("c2_b16_256", 16, 256, 500)]
+CHAIN_GY_CASES = [(f"c2_b16_256_gy_s{s}", 16, 256, s, "gy") for s in (500, 501, 502, 503, 504)]
 CHAIN_NSAMPLE = 2048
 
 
-def gen_steps_chain(cases=CHAIN_CASES, nsample=CHAIN_NSAMPLE):
+# more draws of the same experiment (other data seeds), gradients only, smaller samples: how the HIP / CPU spread ratio is
+# DISTRIBUTED -- at B = 16 a handful of ReLU gates of the few-row bottleneck layers sit within rounding of zero, every fp32
+# evaluation flips its own subset, and one seed is one draw
+CHAIN_SEED_CASES = [(f"c2_b16_256_s{s}", 16, 256, s) for s in (501, 502, 503, 504)]
+
+
+def gen_steps_chain(cases=CHAIN_CASES, nsample=CHAIN_NSAMPLE, kinds=("fwd", "bwd", "grad")):
     """The generator's backward CHAIN at the headline size, layer by layer (round-3 verdict, item 1): the oracle evaluated in
     fp64 -- every layer's output activation, the gradient entering every layer (d loss / d activation), the gradient of the
     generated batch (what the loss stack + discriminator hand the generator) and every parameter gradient, each as a strided
@@ -542,7 +554,7 @@ def gen_steps_chain(cases=CHAIN_CASES, nsample=CHAIN_NSAMPLE):
         stride = max(1, t.numel() // nsample)
         return t[::stride][:nsample].double().clone(), stride
 
-    def run(dtype, b, size, seed0):
+    def run(dtype, b, size, seed0, mode="step"):
         st = Orc.TrainState(0).to(dtype)
         real, mask = synth_batch(b, size, seed0)
         real, mask = real.to(dtype), mask.to(dtype)
@@ -551,10 +563,14 @@ def gen_steps_chain(cases=CHAIN_CASES, nsample=CHAIN_NSAMPLE):
             st.gp[k].requires_grad_(True)
         taps = {}
         gen = Orc.generator_forward(st.gp, real * mask, mask, True, taps)
-        g_loss, _ = Orc.inpainting_loss(st.vp, gen, real, mask, *st.w)
-        g_adv = Orc.bce_logits(Orc.discriminator_forward(st.dp, gen, True), 1.0)
+        if mode == "gy":
+            gy = torch.randn(gen.shape, generator=torch.Generator().manual_seed(5)).to(dtype) / gen.numel()
+            total = (gen * gy).sum()
+        else:
+            g_loss, _ = Orc.inpainting_loss(st.vp, gen, real, mask, *st.w)
+            total = g_loss + Orc.bce_logits(Orc.discriminator_forward(st.dp, gen, True), 1.0)
         names = list(taps)
-        gs = torch.autograd.grad(g_loss + g_adv, [gen] + [taps[n] for n in names] + [st.gp[k] for k in gk])
+        gs = torch.autograd.grad(total, [gen] + [taps[n] for n in names] + [st.gp[k] for k in gk])
         res = {"bwd/gen": (gs[0], True), "fwd/gen": (gen, True)}
         for n, g in zip(names, gs[1:1 + len(names)]):
             res[f"fwd/{n}"] = (taps[n], True)
@@ -563,14 +579,18 @@ def gen_steps_chain(cases=CHAIN_CASES, nsample=CHAIN_NSAMPLE):
             res[f"grad/{k}"] = (g, False)
         outd = {}
         for key, (t, nhwc) in res.items():
+            if key.split("/")[0] not in kinds:
+                continue
             smp, stride = sample_of(t, nhwc)
             td = t.detach().double()
             outd[key] = (smp, stride, float(td.abs().max()), float(td.pow(2).mean().sqrt()), t.numel())
         return outd
 
-    for tag, b, size, seed0 in cases:
-        out[f"{tag}/cfg"] = np.array([b, size, seed0, nsample], dtype=np.int64)
-        r64 = run(torch.float64, b, size, seed0)
+    for case in cases:
+        tag, b, size, seed0 = case[:4]
+        mode = case[4] if len(case) > 4 else "step"
+        out[f"{tag}/cfg"] = np.array([b, size, seed0, nsample, 1 if mode == "gy" else 0], dtype=np.int64)
+        r64 = run(torch.float64, b, size, seed0, mode)
         print(f"  {tag}: fp64 done", flush=True)
         for key, (smp, stride, mx, rms, n) in r64.items():
             out[f"{tag}/{key}/ref"] = smp.numpy()
@@ -584,7 +604,7 @@ def gen_steps_chain(cases=CHAIN_CASES, nsample=CHAIN_NSAMPLE):
             if nthreads:
                 torch.set_num_threads(nthreads)
             with torch.backends.mkldnn.flags(enabled=mkldnn_on):
-                r32 = run(torch.float32, b, size, seed0)
+                r32 = run(torch.float32, b, size, seed0, mode)
             torch.set_num_threads(old_threads)
             for key in r64:
                 d = r32[key][0] - r64[key][0]
@@ -697,7 +717,9 @@ def main():
     jobs = {"steps_unc": gen_steps_unc,           # oracle only: do not need the reference
             "steps_full_unc": lambda: gen_steps_unc(FULL_CASES, with_dp=False, alts=True),
             "models_unc": gen_models_unc,
-            "steps_chain": gen_steps_chain}
+            "steps_chain": gen_steps_chain,
+            "steps_chain_seeds": lambda: gen_steps_chain(CHAIN_SEED_CASES, 512, ("bwd", "grad")),
+            "steps_chain_gy": lambda: gen_steps_chain(CHAIN_GY_CASES, 256, ("bwd", "grad"))}
     if not only or any(n not in jobs for n in only):
         ref_pconv, ref_gen, ref_disc, ref_losses = _load_reference()
         jobs.update(_reference_jobs(ref_pconv, ref_gen, ref_disc, ref_losses))

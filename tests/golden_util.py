@@ -54,11 +54,13 @@ K_UNC = 5.0          # how many fp32-vs-fp64 deviations of the oracle a result m
 K_DRIFT = 20.0       # same, for quantities AFTER an Adam update (steps >= 1): two fp32 trajectories separate chaotically
 _ratios = {}
 _failures = []
+_tensors = {}        # per tensor / quantity: err, the STATED bound alone and the widened bound the test asserts
 
 
 def begin():
     _ratios.clear()
     _failures.clear()
+    _tensors.clear()
 
 
 def expect(ok, msg):
@@ -72,13 +74,24 @@ def finish(name):
     assert not _failures, f"{len(_failures)} parity violations:\n  " + "\n  ".join(str(f) for f in _failures[:40])
 
 
-def record(group, key, ratio, err=None, bound=None):
-    """Keep the worst err/bound ratio per group; tests dump them with dump_ratios() (evidence for the parity report)."""
-    g = _ratios.setdefault(group, {"worst_ratio": 0.0, "worst_key": None, "n": 0})
+def record(group, key, ratio, err=None, bound=None, stated=None):
+    """Keep the worst err/bound ratio per group; tests dump them with dump_ratios() (evidence for the parity report).
+    `stated`: the stated tolerance of SURVEY 8c ALONE (no uncertainty term) -- kept per tensor next to the asserted bound, and
+    counted per group (n_within_stated), so the record says how much of the pass rests on the widening."""
+    g = _ratios.setdefault(group, {"worst_ratio": 0.0, "worst_key": None, "n": 0, "n_stated": 0, "n_within_stated": 0,
+                                   "worst_stated_ratio": 0.0, "worst_stated_key": None})
     g["n"] += 1
     if ratio >= g["worst_ratio"]:
         g.update(worst_ratio=float(ratio), worst_key=key, err=None if err is None else float(err),
                  bound=None if bound is None else float(bound))
+    if stated is not None and err is not None:
+        sr = float(err) / float(stated) if stated > 0 else float("inf")
+        g["n_stated"] += 1
+        g["n_within_stated"] += int(sr <= 1.0)
+        if sr >= g["worst_stated_ratio"]:
+            g.update(worst_stated_ratio=sr, worst_stated_key=key)
+        _tensors[f"{group}:{key}"] = {"err": float(err), "stated_bound": float(stated), "asserted_bound": float(bound),
+                                      "ratio_stated": sr, "ratio_asserted": float(ratio)}
 
 
 def dump_ratios(name):
@@ -89,11 +102,16 @@ def dump_ratios(name):
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, name + ".json"), "w") as f:
             json.dump(_ratios, f, indent=1, sort_keys=True)
+        if _tensors:
+            with open(os.path.join(out, name + "_per_tensor.json"), "w") as f:
+                json.dump(_tensors, f, indent=0, sort_keys=True)
     except OSError:
         pass
     print("\nparity ratios (err / bound, worst per group):")
     for g, v in sorted(_ratios.items()):
-        print(f"  {g:32s} {v['worst_ratio']:.3f}  ({v['worst_key']}, err {v.get('err')}, bound {v.get('bound')}, n={v['n']})")
+        st = f"; within the STATED bound alone: {v['n_within_stated']}/{v['n_stated']}, worst {v['worst_stated_ratio']:.2f} ({v['worst_stated_key']})" \
+            if v.get("n_stated") else ""
+        print(f"  {g:32s} {v['worst_ratio']:.3f}  ({v['worst_key']}, err {v.get('err')}, bound {v.get('bound')}, n={v['n']}){st}")
 
 
 def check_unc(gold, unc, key, t, group, rel=1e-3, atol=1e-10, k=None):
@@ -107,19 +125,19 @@ def check_unc(gold, unc, key, t, group, rel=1e-3, atol=1e-10, k=None):
     if key + "/full" in gold:
         ref = torch.from_numpy(gold[key + "/full"]).double()
         assert ref.numel() == t.numel(), f"{key}: numel {t.numel()} vs {ref.numel()}"
-        checks.append(("max", float((t - ref).abs().max()), bound))
+        checks.append(("max", float((t - ref).abs().max()), bound, rel * gmax + atol))
     else:
         stride = int(gold[key + "/stride"])
         ref = torch.from_numpy(gold[key + "/sample"]).double()
         n = t.numel()
-        checks.append(("sample max", float((t[::stride][:512] - ref).abs().max()), bound))
+        checks.append(("sample max", float((t[::stride][:512] - ref).abs().max()), bound, rel * gmax + atol))
         checks.append(("sum", abs(float(t.sum()) - float(gold[key + "/sum"])),
-                       rel * float(gold[key + "/abssum"]) + k * usum + atol * n))
+                       rel * float(gold[key + "/abssum"]) + k * usum + atol * n, rel * float(gold[key + "/abssum"]) + atol * n))
         l2 = float(gold[key + "/l2"])
-        checks.append(("l2", abs(float(t.norm()) - l2), rel * l2 + k * ul2 + atol * n ** 0.5))
+        checks.append(("l2", abs(float(t.norm()) - l2), rel * l2 + k * ul2 + atol * n ** 0.5, rel * l2 + atol * n ** 0.5))
     worst = 0.0
-    for what, err, bnd in checks:
-        record(group, f"{key} [{what}]", err / bnd, err, bnd)
+    for what, err, bnd, stated in checks:
+        record(group, f"{key} [{what}]", err / bnd, err, bnd, stated=stated)
         expect(err <= bnd, f"{key} [{what}]: err {err:.3e} > bound {bnd:.3e} (oracle fp32-vs-fp64 max dev {umax:.3e}, max|g| {gmax:.3e})")
         worst = max(worst, err / bnd)
     return worst

@@ -22,10 +22,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--tag", default="c2_b16_256")
+    ap.add_argument("--fixture", default="steps_chain")
     args = ap.parse_args()
     import torch
     from tests import chain_util as CU
-    rows = CU.measure_chain(torch.device("cuda:0"), args.tag)
+    rows = CU.measure_chain(torch.device("cuda:0"), args.tag, fixture=args.fixture)
     print(CU.format_table(rows))
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)

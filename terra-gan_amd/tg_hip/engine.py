@@ -40,19 +40,35 @@ VGG_TRUNK = [0, 2, "M", 5, 7, "M", 10, 12, 14]
 # 380 us) and the overlap is paid back on the critical path.  Kept as an opt-in (TG_SIDE_STREAM=1) until the wgrad grid
 # can be confined to a CU subset.  Only used with persistent gradient buffers (outputs never owned by the side stream's
 # allocator pool); inputs are pinned with record_stream so the caching allocator does not recycle them.
-# The frozen VGG16 trunk (perceptual loss only) runs its stride-1 3x3 convolutions as Winograd F(4x4,3x3) (csrc/wino44.inc:
-# 1.78x fewer multiplies than F(2x2,3x3), 6-7x its rms rounding error per layer (max: 1e-5 of the tensor's largest value), inside the perceptual term's fp32 tolerances).
-# TG_VGG_WINO4=0 puts the trunk back on F(2x2,3x3).  Per layer: only where a side has >= 128 channels -- on the 64 -> 64 layer
-# (8 K steps per work item) the heavier output transform eats the gain (measured: forward 0.71 -> 0.70 ms, dgrad 0.37 -> 0.40).
+# The frozen VGG16 trunk (perceptual loss only) and Winograd F(4x4,3x3) (csrc/wino44.inc: 1.78x fewer multiplies than F(2x2,3x3),
+# 6-30x its rounding error per layer -- 1e-6 ... 1e-5 of the tensor's largest value).
+#   * FORWARD: F(2x2,3x3).  The perceptual term is mean |VGG(pred) - VGG(target)| (losses.py:79-90) and its gradient is
+#     sign(fp - ft) pushed back through the trunk; pred equals target outside the holes, so fp - ft is SMALL against the features
+#     over most of the affected region and F(4x4)'s forward error flips those signs wholesale: measured (round 4,
+#     tools/wino4_admission_probe.py, profiles/r04_wino4_probe.json) 21-33 % rms error of d perceptual / d pred against fp64,
+#     for default-initialised and for trained-like weights alike, where F(2x2,3x3) sits at the CPU fp32 evaluation's own error
+#     (0.2-5 %).  Rounds 1-3 had admitted the forward on the loss VALUE and on the train-step fixtures, where at initialisation
+#     the perceptual part of dL/dgen is negligible.  TG_VGG_WINO4_FWD=1 opts back in (throughput experiments only).
+#   * DGRAD: F(4x4,3x3) stays (TG_VGG_WINO4=0 turns it off): the backward is a LINEAR map of the sign pattern, its error enters
+#     once, at 1e-5 of max -- forward F(2x2) + dgrad F(4x4) gives the same gradient error as F(2x2) throughout, to 6 digits.
+#     Per layer only where a side has >= 128 channels: on the 64 -> 64 layer (8 K steps per work item) the heavier output
+#     transform eats the gain (measured: dgrad 0.37 -> 0.40 ms).
 VGG_WINO4 = os.environ.get("TG_VGG_WINO4", "1") != "0"
+VGG_WINO4_FWD = os.environ.get("TG_VGG_WINO4_FWD", "0") == "1"
 VGG_WINO4_MINCH = int(os.environ.get("TG_VGG_WINO4_MINCH", "128"))
 
 
-def _vgg_wino4(w, B, H, W, cout):
-    """... and only when the 16 x 32-pixel x 64-channel work items of that kernel fill the chip (small batches: the F(2x2,3x3)
-    kernel's 16 x 16 items do better)."""
+def _vgg_wino4(w, B, H, W, cout, mode=None, default=True):
+    """F(4x4,3x3) for this launch?  mode None: `default` and only when the 16 x 32-pixel x 64-channel work items of that kernel
+    fill the chip (small batches: the F(2x2,3x3) kernel's 16 x 16 items do better); True: wherever the geometry allows (tests,
+    probes); False: never."""
+    if mode is False or (mode is None and not default):
+        return False
+    wide = max(w.shape[0], w.shape[1]) >= VGG_WINO4_MINCH
+    if mode is True:
+        return wide
     items = B * ((H + 15) // 16) * ((W + 31) // 32) * (cout // 64)
-    return VGG_WINO4 and max(w.shape[0], w.shape[1]) >= VGG_WINO4_MINCH and items >= 256
+    return wide and items >= 256
 _side = {}
 SIDE_WGRAD = os.environ.get("TG_SIDE_STREAM") == "1"
 # Diagnostics (tests/test_hip_backward_chain.py, tools/backward_chain.py): PROBE(kind, name, tensor) is called with every
@@ -380,8 +396,10 @@ def discriminator_replay_running_stats(P, ctx, order=(0,)):
 # --------------------------------------------------------------------------------------------------
 # frozen VGG16 trunk (features[:16]) on a 1-channel image repeated x3 (losses.py:79-90)
 # --------------------------------------------------------------------------------------------------
-def vgg_forward(V, img, keep=True):
-    """V: {'0.weight','0.bias',...,'0.folded'}; img [B][H][W].  Returns (features, ctx)."""
+def vgg_forward(V, img, keep=True, wino4=None):
+    """V: {'0.weight','0.bias',...,'0.folded'}; img [B][H][W].  Returns (features, ctx).
+    wino4 (forward kernels): None = F(2x2,3x3) unless TG_VGG_WINO4_FWD=1 (see the note at the top of this file); True / False
+    force F(4x4,3x3) on (wherever the geometry allows) / off."""
     h = img.reshape(*img.shape, 1)
     steps = []
     for item in VGG_TRUNK:
@@ -393,17 +411,19 @@ def vgg_forward(V, img, keep=True):
             w = V["0.folded"] if item == 0 else V[f"{item}.weight"]
             O.tag(f"vgg{item}.fwd")
             o = O.conv_fwd(h, w, V[f"{item}.bias"], 3, 1, 1, act=O.ACT_RELU,
-                           wino4=_vgg_wino4(w, h.shape[0], h.shape[1], h.shape[2], w.shape[0]))
+                           wino4=_vgg_wino4(w, h.shape[0], h.shape[1], h.shape[2], w.shape[0], wino4, VGG_WINO4_FWD))
             if keep:
                 steps.append(NS(kind="C", w=w, x_shape=tuple(h.shape), a=o))
         h = o
     return h, NS(steps=steps)
 
 
-def vgg_backward(ctx, dfeat, nb=None):
-    """Input gradient only (weights are frozen, losses.py:33-34) for the first `nb` samples."""
+def vgg_backward(ctx, dfeat, nb=None, wino4=None):
+    """Input gradient only (weights are frozen, losses.py:33-34) for the first `nb` samples.
+    wino4 (dgrad kernels): None = F(4x4,3x3) where it pays (TG_VGG_WINO4=0: never); True / False force."""
     da, gated = dfeat, False
     steps = ctx.steps
+    w4 = wino4
     for i in range(len(steps) - 1, -1, -1):
         st = steps[i]
         if st.kind == "M":
@@ -420,9 +440,9 @@ def vgg_backward(ctx, dfeat, nb=None):
             if below is not None and below.kind == "C":      # input of this conv = ReLU output of the conv below
                 ga = below.a if nb is None else below.a[:nb]
                 da = O.conv_dgrad(dy, st.w, shp, 3, 1, 1, gate=ga, gate_act=O.ACT_RELU,
-                                  wino4=_vgg_wino4(st.w, shp[0], shp[1], shp[2], shp[3]))
+                                  wino4=_vgg_wino4(st.w, shp[0], shp[1], shp[2], shp[3], w4, VGG_WINO4))
                 gated = True
             else:
-                da = O.conv_dgrad(dy, st.w, shp, 3, 1, 1, wino4=_vgg_wino4(st.w, shp[0], shp[1], shp[2], shp[3]))
+                da = O.conv_dgrad(dy, st.w, shp, 3, 1, 1, wino4=_vgg_wino4(st.w, shp[0], shp[1], shp[2], shp[3], w4, VGG_WINO4))
                 gated = False
     return da.reshape(da.shape[0], da.shape[1], da.shape[2])

@@ -161,7 +161,9 @@ def gen_pconv(ref_pconv):
 
 # g64 (B = 2): BatchNorm over TWO values at the 1x1 bottleneck -- x_hat = +-1, the gradient through it is rounding noise times
 # a huge rstd: a plumbing case (shapes, odd sizes).  g64b16: the same geometry with 16 values per channel at the bottleneck.
-MODEL_G_CASES = [("g64", 2, 64, 64), ("g72x40", 2, 72, 40), ("g96", 3, 96, 96), ("g64b16", 16, 64, 64)]
+# g72x40b3: the odd-size case (crop / pad in _pad_to_match, generator.py:78-84, forward AND backward) with THREE values per channel
+# at the bottleneck, so that its gradients can be held to values (the B = 2 cases cannot: see test_generator_golden)
+MODEL_G_CASES = [("g64", 2, 64, 64), ("g72x40", 2, 72, 40), ("g96", 3, 96, 96), ("g64b16", 16, 64, 64), ("g72x40b3", 3, 72, 40)]
 
 
 def gen_models(ref_gen, ref_disc):

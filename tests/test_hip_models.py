@@ -56,7 +56,7 @@ def test_pconv_layer_golden(dev, ci):
         GU.check(gold, f"{tag}/y_eval", ye, atol=2e-5, rtol=1e-4)
 
 
-@pytest.mark.parametrize("tag", ["g64b16", "g72x40", "g96", "g64"])
+@pytest.mark.parametrize("tag", ["g64b16", "g72x40", "g72x40b3", "g96", "g64"])
 def test_generator_golden(dev, tag):
     from mvp_gan.src.models.generator import PConvUNet
     from oracle import terragan_oracle as Orc
@@ -79,8 +79,9 @@ def test_generator_golden(dev, tag):
     # The B = 2 cases (g64, g72x40: 1x1 bottleneck) have BatchNorm over exactly TWO values per channel at enc7 / dec7:
     # x_hat = +-1 whatever the inputs, its input-gradient is identically zero in exact arithmetic, and every fp32 evaluation
     # returns rounding noise times rstd ~ 1e3 -- one fp32/fp64 pair is a single draw of that noise, so these two cases use
-    # K_DRIFT x 4 (plumbing checks: shapes, odd sizes, pad/crop, key order).  g96 (B = 3) and g64b16 (g64's geometry with 16
-    # values per channel at the bottleneck) are held to K_UNC like the train-step fixtures (measured worst ratios 0.05 / 0.25).
+    # K_DRIFT x 4 (plumbing checks: shapes, odd sizes, pad/crop, key order).  g96 (B = 3), g64b16 (g64's geometry with 16
+    # values per channel at the bottleneck) and g72x40b3 (the odd-size crop / pad case with B = 3: the only fixture that takes
+    # _pad_to_match through BACKWARD with gradient VALUES checked) are held to K_UNC like the train-step fixtures.
     unc = GU.load("models_unc")
     K = 4 * GU.K_DRIFT if tag in ("g64", "g72x40") else GU.K_UNC
     GU.begin()

@@ -290,6 +290,24 @@ int tg_mul_keep(const float* a, const float* b, float* out, float* a_copy, int64
  * (mean, rstd as written by tg_bn_stats): used when a forward pass is provably identical to one
  * already computed (D(gen) and D(gen.detach()), train.py:202,212) and only its running-stat side
  * effect remains to be reproduced. */
+/* ---- BatchNorm over `groups` passes stacked along the rows: statistics PER PASS, one set of launches -------------------------
+ * The train step stacks D(fake) and D(real) (train.py:202,211) into one forward / one backward; each pass keeps its own batch
+ * statistics (discriminator.py:13: nn.BatchNorm2d in train mode, once per call).  y / out / dout / dy: [groups*rows_per_group][C],
+ * mean / rstd: [groups][C].  Bit-identical to `groups` separate tg_bn_stats + tg_bn_act_fwd (resp. tg_bn_act_bwd) calls whose
+ * parameter gradients are added in pass order.  C % 4 == 0.  No running-statistics side effect: tg_bn_running_update_multi. */
+size_t tg_bn_grouped_ws_bytes(int64_t rows_per_group, int groups, int C);
+int tg_bn_fwd_grouped(const float* y, int64_t rows_per_group, int groups, int C, float eps, const float* gamma,
+                      const float* beta, int act, float slope, float* save_mean, float* save_rstd, float* out,
+                      float* ws, size_t ws_bytes, tg_stream_t stream);
+int tg_bn_act_bwd_grouped(const float* dout, const float* y, int64_t rows_per_group, int groups, int C,
+                          const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                          float slope, float* dy, float* dgamma, float* dbeta, float* dbias, float* ws,
+                          size_t ws_bytes, tg_stream_t stream);
+/* tg_bn_running_update for passes order[0], order[1], ... (indices into mean / rstd [groups][C]) applied one after the other:
+ * the reference updates model.N's buffers in the order D(fake), D(real), D(fake.detach()) (train.py:202,211,212). */
+int tg_bn_running_update_multi(const float* save_mean, const float* save_rstd, int64_t rows_per_group, int C,
+                               float eps, float momentum, const int* order, int norder, float* running_mean,
+                               float* running_var, int64_t* num_batches_tracked, tg_stream_t stream);
 int tg_bn_running_update(const float* save_mean, const float* save_rstd, int64_t rows, int C,
                          float eps, float momentum, float* running_mean, float* running_var,
                          int64_t* num_batches_tracked, tg_stream_t stream);

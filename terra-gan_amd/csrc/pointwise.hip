@@ -90,13 +90,18 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, int64_t rows, int C
 // Vectorised first stage for C % 4 == 0: a thread owns 4 consecutive channels (one 16-byte load per operand and
 // row), the block covers `qpp` channel quads x `rlanes` rows per pass.  Functors implement
 //   void quad(int64_t row, int c0, float (&q)[NQ][4])   // accumulate channels c0..c0+3 of one row
+// GROUPS > 1 (nblocks_g blocks per group): `rows` is the row count of ONE group; the tensor holds the groups back to back and
+// each is reduced exactly as a launch of its own would reduce it (same block geometry, same order: the same bits) -- the
+// stacked D(fake) / D(real) batch of the train step has BatchNorm statistics per pass (engine.discriminator_forward).
 template <int NQ, class F>
-__global__ __launch_bounds__(256) void colreduce4_kernel(F f, int64_t rows, int C, int qpp, int rlanes, int64_t rows_per_block,
-                                                         float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void colreduce4_kernel(F f0, int64_t rows, int C, int qpp, int rlanes, int64_t rows_per_block,
+                                                         float* __restrict__ partial, int nblocks_g) {
     __shared__ float red[NQ][4][256];
     const int tid = threadIdx.x;
     const int cq = tid % qpp, rl = tid / qpp;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int grp = nblocks_g > 0 ? blockIdx.x / nblocks_g : 0;
+    const F f = nblocks_g > 0 ? f0.group(grp, rows) : f0;
+    const int64_t r0 = (int64_t)(blockIdx.x - grp * (nblocks_g > 0 ? nblocks_g : 0)) * rows_per_block;
     const int64_t r1 = min(rows, r0 + rows_per_block);
     const int nquads = C >> 2;
     for (int q0 = 0; q0 < nquads; q0 += qpp) {       // column passes (C > 1024 never happens: one pass for C <= 1024)
@@ -139,8 +144,9 @@ static ColGeom4 col_geom4(int64_t rows, int C) {
     const int nquads = C / 4;
     g.qpp = nquads < 256 ? nquads : 256;
     g.rlanes = 256 / g.qpp;
+    static const int maxgrid = getenv("TG_COLRED_MAXGRID") ? atoi(getenv("TG_COLRED_MAXGRID")) : 512;
     int64_t want = cdiv64(rows, (int64_t)g.rlanes * 8);
-    if (want > 512) want = 512;
+    if (want > maxgrid) want = maxgrid;
     if (want < 1) want = 1;
     g.rows_per_block = cdiv64(rows, want);
     g.grid = (int)cdiv64(rows, g.rows_per_block);
@@ -357,6 +363,7 @@ extern "C" int tg_mask_pyramid(const TgMaskPyramid* pm, int B, tg_stream_t strea
 struct BnStatF {
     const float* y;
     int C;
+    __device__ BnStatF group(int g, int64_t rows_g) const { return BnStatF{y + (size_t)g * rows_g * C, C}; }
     __device__ void operator()(int64_t r, int c, float (&q)[2]) const {
         float d = y[r * C + c] - y[c];
         q[0] += d;
@@ -415,7 +422,7 @@ extern "C" int tg_bn_stats(const float* y, int64_t rows, int C, float eps, float
         ColGeom4 g = col_geom4(rows, C);
         nblocks = g.grid;
         hipLaunchKernelGGL((colreduce4_kernel<2, BnStatF>), dim3(g.grid), dim3(256), 0, S(stream), f, rows, C, g.qpp, g.rlanes,
-                           g.rows_per_block, ws);
+                           g.rows_per_block, ws, 0);
     } else {
         ColGeom g = col_geom(rows, C);
         nblocks = g.grid;
@@ -693,6 +700,11 @@ struct BnBwdF {
     int C, act;
     float slope;
     const float* ratio;   // optional per-row scale of the conv output (partial conv)
+    __device__ BnBwdF group(int g, int64_t rows_g) const {          // per-group statistics live at mean / rstd + g * C
+        const size_t o = (size_t)g * rows_g * C;
+        return BnBwdF{dout + o, y + o, mean + (size_t)g * C, rstd + (size_t)g * C, gamma, beta, C, act, slope,
+                      ratio ? ratio + (size_t)g * rows_g : nullptr};
+    }
     __device__ void operator()(int64_t r, int c, float (&q)[5]) const {
         float xh = (y[r * C + c] - mean[c]) * rstd[c];
         float g = dout[r * C + c] * act_grad(xh * gamma[c] + beta[c], act, slope);
@@ -801,7 +813,7 @@ extern "C" int tg_bn_act_bwd(const float* dout, const float* y, int64_t rows, in
         ColGeom4 g = col_geom4(rows, C);
         nblocks = g.grid;
         hipLaunchKernelGGL((colreduce4_kernel<5, BnBwdF>), dim3(g.grid), dim3(256), 0, S(stream), f, rows, C, g.qpp, g.rlanes,
-                           g.rows_per_block, ws);
+                           g.rows_per_block, ws, 0);
     } else {
         ColGeom g = col_geom(rows, C);
         nblocks = g.grid;
@@ -863,6 +875,13 @@ __device__ __forceinline__ Lerp lerp_src(int dst, int n) {
     return L;
 }
 
+// the bilinear blend, every rounding spelled out (the generic and the x2 kernels must agree bit for bit, whatever the compiler
+// would contract):  ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * c + lx1 * d)
+__device__ __forceinline__ float lerp_blend(float ly0, float ly1, float lx0, float lx1, float a, float b, float c, float d) {
+    const float top = __fmaf_rn(lx1, b, __fmul_rn(lx0, a));
+    const float bot = __fmaf_rn(lx1, d, __fmul_rn(lx0, c));
+    return __fmaf_rn(ly1, bot, __fmul_rn(ly0, top));
+}
 // IDX = the type of the flat element index: uint32_t when the tensor has fewer than 2^31 vector elements (three 64-bit
 // divisions per element made this gather ALU-bound: 3.4 TB/s)
 template <int V, class IDX>  // V = 4 (float4 over channels) or 1
@@ -909,16 +928,77 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict_
                     vc[0] = r1[(int64_t)lx.i0 * Cu]; vd[0] = r1[(int64_t)lx.i1 * Cu];
                 }
 #pragma unroll
-                for (int e = 0; e < V; ++e)
-                    o[e] = ly.l0 * (lx.l0 * va[e] + lx.l1 * vb[e]) + ly.l1 * (lx.l0 * vc[e] + lx.l1 * vd[e]);
+                for (int e = 0; e < V; ++e) o[e] = lerp_blend(ly.l0, ly.l1, lx.l0, lx.l1, va[e], vb[e], vc[e], vd[e]);
             }
         }
         const float mk = omask ? omask[pix] : 1.f;
         if constexpr (V == 4) {
-            const f32x4 o4 = {o[0] * mk, o[1] * mk, o[2] * mk, o[3] * mk};
+            const f32x4 o4 = {__fmul_rn(o[0], mk), __fmul_rn(o[1], mk), __fmul_rn(o[2], mk), __fmul_rn(o[3], mk)};
             *reinterpret_cast<f32x4*>(out + pix * Ct + c) = o4;
         } else {
-            out[pix * Ct + c] = o[0] * mk;
+            out[pix * Ct + c] = __fmul_rn(o[0], mk);
+        }
+    }
+}
+// The exact x2 case (H = 2h, W = 2w, channel counts multiples of 4: every decoder level at the power-of-two tile sizes):
+// one thread per SOURCE pixel and channel quad produces its 2 x 2 output pixels from the 3 x 3 source neighbourhood (9 16-byte
+// loads for 4 outputs instead of 4 per output, two interpolation set-ups per axis instead of one per output element); the
+// skip half of the concat is a second index range of the same launch.  Same interpolation expression, same operand order as
+// upcat_fwd_kernel: bit-identical results (tests/test_hip_ops.py::test_upcat_x2_equals_generic).
+__global__ __launch_bounds__(256) void upcat_fwd_x2_kernel(const float* __restrict__ up, const float* __restrict__ skip,
+                                                           const float* __restrict__ omask, int B, int h, int w, int Cu, int Cs,
+                                                           float* __restrict__ out) {
+    const int Ct = Cu + Cs, H = 2 * h, W = 2 * w;
+    const int cu4 = Cu >> 2, cs4 = Cs >> 2;
+    const uint32_t nA = (uint32_t)B * h * w * cu4, nB = (uint32_t)B * H * W * cs4;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < nA + nB; idx += gridDim.x * 256u) {
+        if (idx < nA) {
+            const int c = (int)(idx % (uint32_t)cu4) * 4;
+            uint32_t t = idx / (uint32_t)cu4;
+            const int x = (int)(t % (uint32_t)w);
+            t /= (uint32_t)w;
+            const int y = (int)(t % (uint32_t)h), b = (int)(t / (uint32_t)h);
+            const int ry[3] = {y > 0 ? y - 1 : 0, y, y < h - 1 ? y + 1 : h - 1};
+            const int rx[3] = {x > 0 ? x - 1 : 0, x, x < w - 1 ? x + 1 : w - 1};
+            f32x4 T[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    T[i][j] = *reinterpret_cast<const f32x4*>(up + (((size_t)b * h + ry[i]) * w + rx[j]) * Cu + c);
+            Lerp ly[2], lx[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                ly[a] = lerp_src(2 * y + a, h);
+                lx[a] = lerp_src(2 * x + a, w);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int i0 = ly[a].i0 - y + 1, i1 = ly[a].i1 - y + 1;          // in {0, 1, 2}: rows y-1, y, y+1 (clamped like ry)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int j0 = lx[bb].i0 - x + 1, j1 = lx[bb].i1 - x + 1;
+                    // register arrays indexed by computed values: select instead (i0 in {0,1}, i1 in {1,2})
+                    const f32x4 a00 = i0 == 0 ? (j0 == 0 ? T[0][0] : T[0][1]) : (j0 == 0 ? T[1][0] : T[1][1]);
+                    const f32x4 a01 = i0 == 0 ? (j1 == 1 ? T[0][1] : T[0][2]) : (j1 == 1 ? T[1][1] : T[1][2]);
+                    const f32x4 a10 = i1 == 1 ? (j0 == 0 ? T[1][0] : T[1][1]) : (j0 == 0 ? T[2][0] : T[2][1]);
+                    const f32x4 a11 = i1 == 1 ? (j1 == 1 ? T[1][1] : T[1][2]) : (j1 == 1 ? T[2][1] : T[2][2]);
+                    const size_t pix = ((size_t)b * H + 2 * y + a) * W + 2 * x + bb;
+                    const float mk = omask ? omask[pix] : 1.f;
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o[e] = __fmul_rn(lerp_blend(ly[a].l0, ly[a].l1, lx[bb].l0, lx[bb].l1, a00[e], a01[e], a10[e], a11[e]), mk);
+                    *reinterpret_cast<f32x4*>(out + pix * Ct + c) = o;
+                }
+            }
+        } else {
+            const uint32_t k = idx - nA;
+            const int c = (int)(k % (uint32_t)cs4) * 4;
+            const size_t pix = k / (uint32_t)cs4;
+            const float mk = omask ? omask[pix] : 1.f;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(skip + pix * Cs + c);
+            *reinterpret_cast<f32x4*>(out + pix * Ct + Cu + c) = f32x4{__fmul_rn(v[0], mk), __fmul_rn(v[1], mk), __fmul_rn(v[2], mk), __fmul_rn(v[3], mk)};
         }
     }
 }
@@ -929,6 +1009,13 @@ extern "C" int tg_upcat_fwd(const float* up, const float* skip, const float* out
     const int offy = floordiv2(H - 2 * h), offx = floordiv2(W - 2 * w);
     const int Ct = Cu + Cs;
     const bool small = (int64_t)B * H * W * Ct < ((int64_t)1 << 31);
+    const bool no_x2 = getenv("TG_NO_UPCAT_X2") != nullptr;      // read per call: tests flip it at run time
+    if (!no_x2 && small && H == 2 * h && W == 2 * w && Cu % 4 == 0 && Cs % 4 == 0) {
+        const int64_t items = (int64_t)B * h * w * (Cu / 4) + (int64_t)B * H * W * (Cs / 4);
+        hipLaunchKernelGGL(upcat_fwd_x2_kernel, dim3(ew_grid(items, 256)), dim3(256), 0, S(stream), up, skip, out_mask, B, h, w, Cu, Cs, out);
+        TG_CHECK_LAUNCH("upcat_fwd_x2_kernel");
+        return TG_OK;
+    }
     if (Cu % 4 == 0 && Cs % 4 == 0) {
         auto kern = small ? upcat_fwd_kernel<4, uint32_t> : upcat_fwd_kernel<4, int64_t>;
         hipLaunchKernelGGL(kern, dim3(ew_grid((int64_t)B * H * W * (Ct / 4), 256)), dim3(256), 0, S(stream), up, skip, out_mask, B, h, w,
@@ -973,9 +1060,9 @@ __global__ __launch_bounds__(256) void upcat_bwd_up_kernel(const float* __restri
                 if constexpr (V == 4) {
                     const f32x4 s4 = *reinterpret_cast<const f32x4*>(src);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] += wy * wx * s4[e];
+                    for (int e = 0; e < 4; ++e) acc[e] = __fmaf_rn(__fmul_rn(wy, wx), s4[e], acc[e]);
                 } else {
-                    acc[0] += wy * wx * src[0];
+                    acc[0] = __fmaf_rn(__fmul_rn(wy, wx), src[0], acc[0]);
                 }
             }
         }
@@ -996,11 +1083,72 @@ __global__ __launch_bounds__(256) void slice_channels_kernel(const float* __rest
         dst[i] = src[r * Ct + c0 + c];
     }
 }
+// x2 case of the adjoint (see upcat_fwd_x2_kernel): the four row / column weights of the 4 x 4 output neighbourhood are set up
+// once per thread (8 interpolation set-ups instead of 20), accumulated in the generic kernel's order (bit-identical); the skip
+// half of the gradient (a channel slice of dout) is a second index range of the same launch instead of a second kernel.
+__global__ __launch_bounds__(256) void upcat_bwd_x2_kernel(const float* __restrict__ dout, int B, int h, int w, int Cu, int Cs,
+                                                           float* __restrict__ dup, float* __restrict__ dskip) {
+    const int Ct = Cu + Cs, H = 2 * h, W = 2 * w;
+    const int cu4 = Cu >> 2, cs4 = dskip ? Cs >> 2 : 0;
+    const uint32_t nA = (uint32_t)B * h * w * cu4, nB = (uint32_t)B * H * W * cs4;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < nA + nB; idx += gridDim.x * 256u) {
+        if (idx < nA) {
+            const int c = (int)(idx % (uint32_t)cu4) * 4;
+            uint32_t t = idx / (uint32_t)cu4;
+            const int x = (int)(t % (uint32_t)w);
+            t /= (uint32_t)w;
+            const int y = (int)(t % (uint32_t)h), b = (int)(t / (uint32_t)h);
+            float wy[4], wx[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int yu = 2 * y - 1 + k, xu = 2 * x - 1 + k;
+                wy[k] = 0.f;
+                wx[k] = 0.f;
+                if (yu >= 0 && yu < H) {
+                    const Lerp l = lerp_src(yu, h);
+                    wy[k] = (l.i0 == y ? l.l0 : 0.f) + (l.i1 == y ? l.l1 : 0.f);
+                }
+                if (xu >= 0 && xu < W) {
+                    const Lerp l = lerp_src(xu, w);
+                    wx[k] = (l.i0 == x ? l.l0 : 0.f) + (l.i1 == x ? l.l1 : 0.f);
+                }
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                if (wy[ky] == 0.f) continue;
+                const int yu = 2 * y - 1 + ky;
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    if (wx[kx] == 0.f) continue;
+                    const int xu = 2 * x - 1 + kx;
+                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(dout + (((size_t)b * H + yu) * W + xu) * Ct + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = __fmaf_rn(__fmul_rn(wy[ky], wx[kx]), s4[e], acc[e]);
+                }
+            }
+            *reinterpret_cast<f32x4*>(dup + (((size_t)b * h + y) * w + x) * Cu + c) = acc;
+        } else {
+            const uint32_t k = idx - nA;
+            const int c = (int)(k % (uint32_t)cs4) * 4;
+            const size_t pix = k / (uint32_t)cs4;
+            *reinterpret_cast<f32x4*>(dskip + pix * Cs + c) = *reinterpret_cast<const f32x4*>(dout + pix * Ct + Cu + c);
+        }
+    }
+}
 extern "C" int tg_upcat_bwd(const float* dout, int B, int h, int w, int Cu, int H, int W, int Cs, float* dup, float* dskip,
                             tg_stream_t stream) {
     TG_REQUIRE(dout && dup && B > 0 && h > 0 && w > 0 && Cu > 0 && H > 0 && W > 0 && Cs >= 0, "tg_upcat_bwd: bad arguments");
     const int offy = floordiv2(H - 2 * h), offx = floordiv2(W - 2 * w);
     const int Ct = Cu + Cs;
+    const bool no_x2 = getenv("TG_NO_UPCAT_X2") != nullptr;      // read per call: tests flip it at run time
+    if (!no_x2 && H == 2 * h && W == 2 * w && Cu % 4 == 0 && Cs % 4 == 0 && (int64_t)B * H * W * Ct < ((int64_t)1 << 31)) {
+        const int64_t items = (int64_t)B * h * w * (Cu / 4) + (dskip ? (int64_t)B * H * W * (Cs / 4) : 0);
+        hipLaunchKernelGGL(upcat_bwd_x2_kernel, dim3(ew_grid(items, 256)), dim3(256), 0, S(stream), dout, B, h, w, Cu, Cs, dup,
+                           Cs > 0 ? dskip : nullptr);
+        TG_CHECK_LAUNCH("upcat_bwd_x2_kernel");
+        return TG_OK;
+    }
     if (Cu % 4 == 0 && Ct % 4 == 0) {
         hipLaunchKernelGGL((upcat_bwd_up_kernel<4>), dim3(ew_grid((int64_t)B * h * w * (Cu / 4), 256)), dim3(256), 0, S(stream),
                            dout, B, h, w, Cu, H, W, Ct, offy, offx, dup);
@@ -1583,6 +1731,204 @@ extern "C" int tg_bn_running_update(const float* save_mean, const float* save_rs
     hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), save_mean, save_rstd, (double)rows,
                        C, eps, momentum, running_mean, running_var, num_batches_tracked);
     TG_CHECK_LAUNCH("bn_running_update_kernel");
+    return TG_OK;
+}
+
+// ---- BatchNorm over `groups` passes stacked along the rows (statistics per pass) in ONE set of launches ---------------------------
+// The train step runs D(fake) and D(real) as one stacked forward and their backward passes as one (train.py:202,211-218): the
+// convolutions see 2B images, BatchNorm must see each pass by itself.  Per layer that was 2 x (reduce, finalise, apply) forward and
+// 2 x (reduce, finalise, apply) + 3 accumulations backward; here: one reduce (groups side by side), one finalise, one apply --
+// 6 launches instead of 15, bit-identical (same block geometry and summation order per group; parameter gradients summed in pass order).
+__global__ __launch_bounds__(256) void bn_finalize_grouped_kernel(const float* __restrict__ partial, int nblocks_g, int groups, int C,
+                                                                  const float* __restrict__ y, int64_t rows_g, float eps,
+                                                                  float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    for (int g = 0; g < groups; ++g) {
+        double q[2];
+        int c;
+        const bool own = final_reduce<2>(partial + (size_t)g * nblocks_g * 2 * C, nblocks_g, C, q, &c);
+        if (own) {
+            const double n = (double)rows_g;
+            const double md = q[0] / n;
+            double var = q[1] / n - md * md;
+            if (var < 0.0) var = 0.0;
+            mean_out[g * C + c] = (float)((double)y[(size_t)g * rows_g * C + c] + md);
+            rstd_out[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        __syncthreads();                       // final_reduce's LDS is reused by the next group
+    }
+}
+__global__ __launch_bounds__(256) void bn_act_fwd4_grouped_kernel(const float* __restrict__ y, int64_t rows_g, int C, int qpp, int rlanes,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  int act, float slope, float* __restrict__ out) {
+    const int cq = threadIdx.x % qpp, rl = threadIdx.x / qpp;
+    if (rl >= rlanes) return;
+    const int g = blockIdx.z, nquads = C >> 2;
+    const float* yg = y + (size_t)g * rows_g * C;
+    float* og = out + (size_t)g * rows_g * C;
+    for (int q0 = blockIdx.y * qpp; q0 < nquads; q0 += gridDim.y * qpp) {
+        const int c0 = (q0 + cq) * 4;
+        if (c0 >= C) continue;
+        const f32x4 mv = *reinterpret_cast<const f32x4*>(mean + g * C + c0), rv = *reinterpret_cast<const f32x4*>(rstd + g * C + c0);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + c0), bv = *reinterpret_cast<const f32x4*>(beta + c0);
+        for (int64_t r = (int64_t)blockIdx.x * rlanes + rl; r < rows_g; r += (int64_t)gridDim.x * rlanes) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(yg + r * C + c0);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = apply_act((v[e] - mv[e]) * rv[e] * gv[e] + bv[e], act, slope);
+            *reinterpret_cast<f32x4*>(og + r * C + c0) = o;
+        }
+    }
+}
+extern "C" size_t tg_bn_grouped_ws_bytes(int64_t rows_per_group, int groups, int C) {
+    if (rows_per_group <= 0 || groups <= 0 || C <= 0 || C % 4) return 0;
+    const ColGeom4 g = col_geom4(rows_per_group, C);
+    // partials of every group + (backward) the per-group dgamma / dbeta the apply pass reads
+    return (align_up((size_t)groups * g.grid * 5 * C, 64) + align_up((size_t)groups * 2 * C, 64)) * sizeof(float);
+}
+extern "C" int tg_bn_fwd_grouped(const float* y, int64_t rows_per_group, int groups, int C, float eps, const float* gamma,
+                                 const float* beta, int act, float slope, float* save_mean, float* save_rstd, float* out,
+                                 float* ws, size_t ws_bytes, tg_stream_t stream) {
+    TG_REQUIRE(y && gamma && beta && save_mean && save_rstd && out && ws, "tg_bn_fwd_grouped: null pointer");
+    TG_REQUIRE(groups >= 1 && groups <= 8 && C >= 4 && C <= 1024 && C % 4 == 0, "tg_bn_fwd_grouped: groups=%d C=%d unsupported", groups, C);
+    TG_REQUIRE(rows_per_group > 1, "tg_bn_fwd_grouped: Expected more than 1 value per channel when training");
+    TG_REQUIRE(ws_bytes >= tg_bn_grouped_ws_bytes(rows_per_group, groups, C), "tg_bn_fwd_grouped: workspace too small");
+    const ColGeom4 g = col_geom4(rows_per_group, C);
+    BnStatF f{y, C};
+    hipLaunchKernelGGL((colreduce4_kernel<2, BnStatF>), dim3(g.grid * groups), dim3(256), 0, S(stream), f, rows_per_group, C, g.qpp,
+                       g.rlanes, g.rows_per_block, ws, g.grid);
+    TG_CHECK_LAUNCH("bn_stats_grouped");
+    hipLaunchKernelGGL(bn_finalize_grouped_kernel, dim3(fr_grid(C)), dim3(256), 0, S(stream), ws, g.grid, groups, C, y, rows_per_group,
+                       eps, save_mean, save_rstd);
+    TG_CHECK_LAUNCH("bn_finalize_grouped");
+    RowGeom rg = row_geom(rows_per_group, C);
+    rg.grid.z = groups;
+    hipLaunchKernelGGL(bn_act_fwd4_grouped_kernel, rg.grid, dim3(256), 0, S(stream), y, rows_per_group, C, rg.qpp, rg.rlanes, save_mean,
+                       save_rstd, gamma, beta, act, slope, out);
+    TG_CHECK_LAUNCH("bn_act_fwd4_grouped");
+    return TG_OK;
+}
+
+// backward: per-group sums -> per-group dgamma_g / dbeta_g (what the apply pass of that group needs) in `gws`, parameter gradients
+// = sum over the groups in pass order (fp32, exactly what accumulating the separate passes' results gave)
+__global__ __launch_bounds__(256) void bn_bwd_final_grouped_kernel(const float* __restrict__ partial, int nblocks_g, int groups, int C,
+                                                                   double n, const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                                   float* __restrict__ gws, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, float* __restrict__ dbias) {
+    float sg = 0.f, sb = 0.f, sd = 0.f;
+    int c = 0;
+    bool own = false;
+    for (int g = 0; g < groups; ++g) {
+        double q[5];
+        own = final_reduce<5>(partial + (size_t)g * nblocks_g * 5 * C, nblocks_g, C, q, &c);
+        if (own) {
+            const float db_ = (float)q[0], dg_ = (float)q[1];
+            gws[(g * 2 + 0) * C + c] = dg_;
+            gws[(g * 2 + 1) * C + c] = db_;
+            const float dbi = (float)((double)gamma[c] * (double)rstd[g * C + c] * (q[2] - q[0] / n * q[4] - q[1] / n * q[3]));
+            sg = g == 0 ? dg_ : dg_ + sg;          // axpby(x = this pass, y = running sum): 1*x + 1*y
+            sb = g == 0 ? db_ : db_ + sb;
+            sd = g == 0 ? dbi : dbi + sd;
+        }
+        __syncthreads();
+    }
+    if (own) {
+        dgamma[c] = sg;
+        dbeta[c] = sb;
+        if (dbias) dbias[c] = sd;
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply4_grouped_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                                    int64_t rows_g, int C, int qpp, int rlanes,
+                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    int act, float slope, const float* __restrict__ gws,
+                                                                    float* __restrict__ dy) {
+    const int cq = threadIdx.x % qpp, rl = threadIdx.x / qpp;
+    if (rl >= rlanes) return;
+    const int g = blockIdx.z;
+    const size_t o = (size_t)g * rows_g * C;
+    const float inv_n = 1.0f / (float)rows_g;
+    const int nquads = C >> 2;
+    for (int q0 = blockIdx.y * qpp; q0 < nquads; q0 += gridDim.y * qpp) {
+        const int c0 = (q0 + cq) * 4;
+        if (c0 >= C) continue;
+        const f32x4 mv = *reinterpret_cast<const f32x4*>(mean + g * C + c0), rv = *reinterpret_cast<const f32x4*>(rstd + g * C + c0);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + c0), bv = *reinterpret_cast<const f32x4*>(beta + c0);
+        const f32x4 dgv = *reinterpret_cast<const f32x4*>(gws + (g * 2 + 0) * C + c0), dbv = *reinterpret_cast<const f32x4*>(gws + (g * 2 + 1) * C + c0);
+        for (int64_t r = (int64_t)blockIdx.x * rlanes + rl; r < rows_g; r += (int64_t)gridDim.x * rlanes) {
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o + r * C + c0);
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(dout + o + r * C + c0);
+            f32x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float xh = (yv[e] - mv[e]) * rv[e];
+                float gg = dv[e] * act_grad(xh * gv[e] + bv[e], act, slope);
+                ov[e] = gv[e] * rv[e] * (gg - dbv[e] * inv_n - xh * dgv[e] * inv_n) * 1.f;
+            }
+            *reinterpret_cast<f32x4*>(dy + o + r * C + c0) = ov;
+        }
+    }
+}
+extern "C" int tg_bn_act_bwd_grouped(const float* dout, const float* y, int64_t rows_per_group, int groups, int C, const float* mean,
+                                     const float* rstd, const float* gamma, const float* beta, int act, float slope, float* dy,
+                                     float* dgamma, float* dbeta, float* dbias, float* ws, size_t ws_bytes, tg_stream_t stream) {
+    TG_REQUIRE(dout && y && mean && rstd && gamma && beta && dy && dgamma && dbeta && ws, "tg_bn_act_bwd_grouped: null pointer");
+    TG_REQUIRE(groups >= 1 && groups <= 8 && C >= 4 && C <= 1024 && C % 4 == 0 && rows_per_group > 0, "tg_bn_act_bwd_grouped: bad dims");
+    TG_REQUIRE(ws_bytes >= tg_bn_grouped_ws_bytes(rows_per_group, groups, C), "tg_bn_act_bwd_grouped: workspace too small");
+    const ColGeom4 g = col_geom4(rows_per_group, C);
+    float* gws = ws + align_up((size_t)groups * g.grid * 5 * C, 64);
+    BnBwdF f{dout, y, mean, rstd, gamma, beta, C, act, slope, nullptr};
+    hipLaunchKernelGGL((colreduce4_kernel<5, BnBwdF>), dim3(g.grid * groups), dim3(256), 0, S(stream), f, rows_per_group, C, g.qpp,
+                       g.rlanes, g.rows_per_block, ws, g.grid);
+    TG_CHECK_LAUNCH("bn_bwd_reduce_grouped");
+    hipLaunchKernelGGL(bn_bwd_final_grouped_kernel, dim3(fr_grid(C)), dim3(256), 0, S(stream), ws, g.grid, groups, C, (double)rows_per_group,
+                       gamma, rstd, gws, dgamma, dbeta, dbias);
+    TG_CHECK_LAUNCH("bn_bwd_final_grouped");
+    RowGeom rg = row_geom(rows_per_group, C);
+    rg.grid.z = groups;
+    hipLaunchKernelGGL(bn_bwd_apply4_grouped_kernel, rg.grid, dim3(256), 0, S(stream), dout, y, rows_per_group, C, rg.qpp, rg.rlanes, mean,
+                       rstd, gamma, beta, act, slope, gws, dy);
+    TG_CHECK_LAUNCH("bn_bwd_apply4_grouped");
+    return TG_OK;
+}
+
+// running-statistics updates of several passes, applied one after the other in `order` (indices into the per-group statistics) by
+// ONE launch: the reference's D(fake), D(real), D(fake.detach()) update model.N's buffers in that order (train.py:202,211,212)
+struct TgBnOrder { int n; int idx[8]; };
+__global__ __launch_bounds__(256) void bn_running_update_multi_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                      double n, int C, float eps, float momentum, TgBnOrder ord,
+                                                                      float* __restrict__ rm, float* __restrict__ rv,
+                                                                      int64_t* __restrict__ nbt) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && nbt) *nbt += ord.n;
+    if (c >= C) return;
+    float m_ = rm[c], v_ = rv[c];
+    for (int k = 0; k < ord.n; ++k) {
+        const int g = ord.idx[k];
+        const double r = (double)rstd[g * C + c];
+        double var = 1.0 / (r * r) - (double)eps;
+        if (var < 0.0) var = 0.0;
+        m_ = (float)((1.0 - (double)momentum) * (double)m_ + (double)momentum * (double)mean[g * C + c]);
+        v_ = (float)((1.0 - (double)momentum) * (double)v_ + (double)momentum * var * (n / (n - 1.0)));
+    }
+    rm[c] = m_;
+    rv[c] = v_;
+}
+extern "C" int tg_bn_running_update_multi(const float* save_mean, const float* save_rstd, int64_t rows_per_group, int C, float eps,
+                                          float momentum, const int* order, int norder, float* running_mean, float* running_var,
+                                          int64_t* num_batches_tracked, tg_stream_t stream) {
+    TG_REQUIRE(save_mean && save_rstd && running_mean && running_var && order && rows_per_group > 1 && C > 0 && norder >= 1 && norder <= 8,
+               "tg_bn_running_update_multi: bad arguments");
+    TgBnOrder ord = {};
+    ord.n = norder;
+    for (int k = 0; k < norder; ++k) {
+        TG_REQUIRE(order[k] >= 0 && order[k] < 8, "tg_bn_running_update_multi: order[%d] = %d", k, order[k]);
+        ord.idx[k] = order[k];
+    }
+    hipLaunchKernelGGL(bn_running_update_multi_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), save_mean, save_rstd,
+                       (double)rows_per_group, C, eps, momentum, ord, running_mean, running_var, num_batches_tracked);
+    TG_CHECK_LAUNCH("bn_running_update_multi_kernel");
     return TG_OK;
 }
 

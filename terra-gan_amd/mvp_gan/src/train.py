@@ -146,6 +146,11 @@ def _train_step(generator, discriminator, criterion, optimizer_G, optimizer_D, r
     optimizer_G.zero_grad()                                                  # set_to_none (App. A #12)
     gen, gctx = E.generator_forward(GP, masked, mask, generator.training,
                                     checkpoint=getattr(generator, "activation_checkpointing", False), out=both[:B])     # train.py:185
+    if grad_sync is not None and grad_sync._inflight != 0:
+        # The loss stack's dgrads run on wino44_kernel, the one persistent Winograd kernel WITHOUT a work-stealing variant
+        # (csrc/wino44.inc): that is sound only while no gradient bucket is in flight here -- every bucket of the previous step
+        # was waited for by its hip_adam_step, and this step's first bucket is launched inside generator_backward below.
+        raise RuntimeError(f"train_step: {grad_sync._inflight} gradient collectives still in flight at the loss stack")
     g_loss, _parts, dgen = criterion_forward(criterion, gen, real, mask, want_grad=True, both=both)   # train.py:188
     # D(fake) of this step (train.py:202), D(real) and D(fake.detach()) of the discriminator step (train.py:211-212) see the
     # same discriminator weights, and D(real) depends on nothing the generator step produces: the two distinct passes are

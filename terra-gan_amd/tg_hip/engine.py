@@ -288,6 +288,18 @@ def discriminator_forward(P, img, training=True, groups=1, update_running=True):
             layers.append(NS(ci=ci, bi=None, k=k, s=s, p=p, x=h, a=a, act=act))
         else:
             y = O.conv_fwd(h, w, b, k, s, p)
+            if groups > 1 and training and y.shape[-1] % 4 == 0:
+                # statistics per pass, ONE set of launches for all passes (tg_bn_fwd_grouped); running statistics by replay
+                mean2, rstd2, a = O.bn_fwd_grouped(y, groups, P[f"model.{bi}.weight"], P[f"model.{bi}.bias"], O.ACT_LEAKY, 0.2)
+                if update_running:
+                    O.bn_running_update_multi(mean2, rstd2, y.numel() // y.shape[-1] // groups, list(range(groups)),
+                                              P[f"model.{bi}.running_mean"], P[f"model.{bi}.running_var"],
+                                              P[f"model.{bi}.num_batches_tracked"])
+                means, rstds = [mean2[gi] for gi in range(groups)], [rstd2[gi] for gi in range(groups)]
+                layers.append(NS(ci=ci, bi=bi, k=k, s=s, p=p, x=h, y=y, mean=means[0], rstd=rstds[0], means=means, rstds=rstds,
+                                 mean2=mean2, rstd2=rstd2, a=a))
+                h = a
+                continue
             a = torch.empty_like(y)
             means, rstds = [], []
             for gi in range(groups):
@@ -336,7 +348,10 @@ def discriminator_backward(P, ctx, dlogits, want_wgrad=True, want_dimg=False, gb
             outs = (gbuf[f"model.{c.bi}.weight"], gbuf[f"model.{c.bi}.bias"], gbuf[f"model.{c.ci}.bias"]) \
                 if (gbuf is not None and want_wgrad) else None
             G_ = getattr(ctx, "groups", 1)
-            if G_ == 1:
+            if G_ > 1 and hasattr(c, "mean2"):
+                dy, dgamma, dbeta, db = O.bn_act_bwd_grouped(da, c.y, G_, c.mean2, c.rstd2, P[f"model.{c.bi}.weight"],
+                                                             P[f"model.{c.bi}.bias"], O.ACT_LEAKY, 0.2, want_dbias=want_wgrad, outs=outs)
+            elif G_ == 1:
                 dy, dgamma, dbeta, db = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"model.{c.bi}.weight"], P[f"model.{c.bi}.bias"],
                                                      O.ACT_LEAKY, 0.2, want_dbias=want_wgrad, outs=outs)
             else:
@@ -387,6 +402,10 @@ def discriminator_replay_running_stats(P, ctx, order=(0,)):
     for c in ctx.layers:
         if c.bi is not None:
             rows = c.y.numel() // c.y.shape[-1] // G_
+            if hasattr(c, "mean2"):
+                O.bn_running_update_multi(c.mean2, c.rstd2, rows, list(order), P[f"model.{c.bi}.running_mean"],
+                                          P[f"model.{c.bi}.running_var"], P[f"model.{c.bi}.num_batches_tracked"])
+                continue
             for gi in order:
                 mean, rstd = (c.means[gi], c.rstds[gi]) if hasattr(c, "means") else (c.mean, c.rstd)
                 O.bn_running_update(mean, rstd, rows, P[f"model.{c.bi}.running_mean"], P[f"model.{c.bi}.running_var"],

@@ -8,7 +8,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libterragan_hip.so")
+# TG_HIP_LIB: another build of the SAME library (timing probes of kernel variants, tools/); never a different implementation
+LIB_PATH = os.environ.get("TG_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libterragan_hip.so")
 
 
 class TgConv(C.Structure):
@@ -86,6 +87,10 @@ SIGNATURES = {
     "tg_mul": (I, [P, P, P, I64, P]),
     "tg_mul_keep": (I, [P, P, P, P, I64, P]),
     "tg_bn_running_update": (I, [P, P, I64, I, F, F, P, P, P, P]),
+    "tg_bn_grouped_ws_bytes": (SZ, [I64, I, I]),
+    "tg_bn_fwd_grouped": (I, [P, I64, I, I, F, P, P, I, F, P, P, P, P, SZ, P]),
+    "tg_bn_act_bwd_grouped": (I, [P, P, I64, I, I, P, P, P, P, I, F, P, P, P, P, P, SZ, P]),
+    "tg_bn_running_update_multi": (I, [P, P, I64, I, F, F, C.POINTER(C.c_int), I, P, P, P, P]),
     "tg_quality_metrics_ws_bytes": (SZ, [I64, I, I]),
     "tg_quality_metrics": (I, [P, P, P, I64, I, I, P, P, SZ, P]),
     "tg_u8_to_tiles": (I, [P, P, I64, P, P, P]),

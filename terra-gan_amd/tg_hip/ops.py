@@ -418,6 +418,49 @@ def bn_running_update(mean, rstd, rows, running_mean, running_var, nbt, eps=BN_E
                                         _p(running_var), nbt_p, _stream()), "tg_bn_running_update")
 
 
+def bn_fwd_grouped(y, groups, gamma, beta, act, slope=0.0, out=None, eps=BN_EPS):
+    """Training-mode BatchNorm of `groups` passes stacked along the leading dimension, statistics per pass, in one set of launches
+    (tg_bn_fwd_grouped).  -> (mean [groups, C], rstd [groups, C], out).  No running-statistics update (bn_running_update_multi)."""
+    _chk(y, "y"); _chk(out, "out")
+    Cc = y.shape[-1]
+    rows_g = y.numel() // Cc // groups
+    assert rows_g * groups * Cc == y.numel() and y.shape[0] % groups == 0
+    mean, rstd = empty(groups, Cc, like=y), empty(groups, Cc, like=y)
+    if out is None:
+        out = torch.empty_like(y)
+    lib = _lib()
+    ws = workspace(lib.tg_bn_grouped_ws_bytes(rows_g, groups, Cc))
+    L.check(lib.tg_bn_fwd_grouped(_p(y), rows_g, groups, Cc, eps, _p(gamma.detach()), _p(beta.detach()), act, slope, _p(mean), _p(rstd),
+                                  _p(out), _p(ws), ws.numel() * 4, _stream()), "tg_bn_fwd_grouped")
+    return mean, rstd, out
+
+
+def bn_act_bwd_grouped(dout, y, groups, mean, rstd, gamma, beta, act, slope=0.0, want_dbias=True, outs=None):
+    """Backward of bn_fwd_grouped, in place on dout.  -> (dy, dgamma, dbeta, dbias): parameter gradients summed over the passes."""
+    _chk(dout, "dout"); _chk(y, "y"); _chk(mean, "mean"); _chk(rstd, "rstd")
+    Cc = y.shape[-1]
+    rows_g = y.numel() // Cc // groups
+    if outs is not None:
+        dgamma, dbeta, dbias = outs
+    else:
+        dgamma, dbeta = empty(Cc, like=y), empty(Cc, like=y)
+        dbias = empty(Cc, like=y) if want_dbias else None
+    lib = _lib()
+    ws = workspace(lib.tg_bn_grouped_ws_bytes(rows_g, groups, Cc))
+    L.check(lib.tg_bn_act_bwd_grouped(_p(dout), _p(y), rows_g, groups, Cc, _p(mean), _p(rstd), _p(gamma.detach()), _p(beta.detach()), act,
+                                      slope, _p(dout), _p(dgamma), _p(dbeta), _p(dbias), _p(ws), ws.numel() * 4, _stream()),
+            "tg_bn_act_bwd_grouped")
+    return dout, dgamma, dbeta, dbias
+
+
+def bn_running_update_multi(mean, rstd, rows_g, order, running_mean, running_var, nbt, eps=BN_EPS, momentum=BN_MOMENTUM):
+    """Running-statistics updates of passes `order` (indices into mean / rstd [groups, C]), one after the other, in ONE launch."""
+    arr = (C.c_int * len(order))(*order)
+    nbt_p = None if nbt is None else C.c_void_p(nbt.data_ptr())
+    L.check(_lib().tg_bn_running_update_multi(_p(mean), _p(rstd), rows_g, mean.shape[-1], eps, momentum, arr, len(order),
+                                              _p(running_mean), _p(running_var), nbt_p, _stream()), "tg_bn_running_update_multi")
+
+
 def bn_act_fwd(y, mean, rstd, gamma, beta, act, slope=0.0, out=None):
     _chk(y, "y"); _chk(out, "out")
     Cc = y.shape[-1]

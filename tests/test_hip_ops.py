@@ -152,6 +152,73 @@ def test_upcat_fwd_bwd(dev, shape, delta):
     assert torch.equal(mm.cpu(), torch.maximum(un, sm)[:, 0])
 
 
+@pytest.mark.parametrize("rows_g,C,groups", [(4096, 512, 2), (16384, 256, 2), (2100, 128, 3), (65536, 128, 2)])
+def test_grouped_batchnorm_equals_per_pass_calls(dev, rows_g, C, groups):
+    """tg_bn_fwd_grouped / tg_bn_act_bwd_grouped / tg_bn_running_update_multi (the stacked D(fake) / D(real) passes of the train
+    step: statistics per pass, one set of launches) against the per-pass calls they replace, bit for bit: outputs, statistics,
+    the in-place input gradient, parameter gradients accumulated in pass order, running statistics replayed in a given order."""
+    from tg_hip import ops as O
+    g = torch.Generator().manual_seed(rows_g + C)
+    y = (torch.randn(groups * rows_g, C, generator=g) * 2 + torch.randn(C, generator=g)).reshape(groups, rows_g, 1, C).to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.2).to(dev)
+    da = torch.randn(groups, rows_g, 1, C, generator=g).to(dev)
+    mean2, rstd2, a2 = O.bn_fwd_grouped(y, groups, gamma, beta, O.ACT_LEAKY, 0.2)
+    d2 = da.clone()
+    _dy, dg2, db2, dbi2 = O.bn_act_bwd_grouped(d2, y, groups, mean2, rstd2, gamma, beta, O.ACT_LEAKY, 0.2)
+    order = [0, 1, 0] if groups == 2 else [2, 0, 1, 1]
+    rm2, rv2, nbt2 = torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros((), dtype=torch.long, device=dev)
+    O.bn_running_update_multi(mean2, rstd2, rows_g, order, rm2, rv2, nbt2)
+    # the per-pass calls
+    rm1, rv1, nbt1 = torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.zeros((), dtype=torch.long, device=dev)
+    stats, dg1 = [], None
+    for gi in range(groups):
+        mean, rstd = O.bn_stats(y[gi])
+        a1 = O.bn_act_fwd(y[gi], mean, rstd, gamma, beta, O.ACT_LEAKY, 0.2)
+        assert torch.equal(mean, mean2[gi]) and torch.equal(rstd, rstd2[gi]) and torch.equal(a1, a2[gi])
+        d1 = da[gi].clone()
+        _d, g1, b1, bi1 = O.bn_act_bwd(d1, y[gi], mean, rstd, gamma, beta, O.ACT_LEAKY, 0.2)
+        assert torch.equal(d1, d2[gi])
+        if gi == 0:
+            dg1, db1, dbi1 = g1, b1, bi1
+        else:
+            O.axpby_(g1, 1.0, 1.0, dg1), O.axpby_(b1, 1.0, 1.0, db1), O.axpby_(bi1, 1.0, 1.0, dbi1)
+        stats.append((mean, rstd))
+    assert torch.equal(dg1, dg2) and torch.equal(db1, db2) and torch.equal(dbi1, dbi2)
+    for gi in order:
+        O.bn_running_update(stats[gi][0], stats[gi][1], rows_g, rm1, rv1, nbt1)
+    assert torch.equal(rm1, rm2) and torch.equal(rv1, rv2) and int(nbt1) == int(nbt2) == len(order)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 8, 4), (2, 9, 6, 64, 64), (2, 3, 5, 4, 0), (1, 1, 1, 8, 4), (3, 16, 16, 128, 64), (1, 1, 6, 4, 4)])
+def test_upcat_x2_equals_generic(dev, shape):
+    """The exact x2 kernels (one thread per SOURCE pixel: upcat_fwd_x2_kernel / upcat_bwd_x2_kernel, skip half in the same
+    launch) against the generic per-output-element gather on the same inputs: same interpolation expression, same operand
+    order -- equal bit for bit, forward, upsample adjoint and skip slice.  TG_NO_UPCAT_X2 is read per call."""
+    import os
+    from tg_hip import ops as O
+    B, h, w, Cu, Cs = shape
+    g = torch.Generator().manual_seed(11)
+    up = torch.randn(B, h, w, Cu, generator=g).to(dev)
+    skip = torch.randn(B, 2 * h, 2 * w, Cs, generator=g).to(dev) if Cs else None
+    om = (torch.rand(B, 2 * h, 2 * w, generator=g) > 0.3).float().to(dev)
+    dcat = torch.randn(B, 2 * h, 2 * w, Cu + Cs, generator=g).to(dev)
+    res = {}
+    for mode in ("x2", "generic"):
+        if mode == "generic":
+            os.environ["TG_NO_UPCAT_X2"] = "1"
+        try:
+            out = O.upcat_fwd(up, skip, 2 * h, 2 * w, out_mask=om)
+            out_nm = O.upcat_fwd(up, skip, 2 * h, 2 * w)
+            dup, dskip = O.upcat_bwd(dcat, h, w, Cu)
+        finally:
+            os.environ.pop("TG_NO_UPCAT_X2", None)
+        res[mode] = (out, out_nm, dup, dskip)
+    for a, b in zip(res["x2"], res["generic"]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("shape", [(2, 8, 8, 4), (1, 7, 9, 3), (2, 5, 6, 64), (1, 2, 2, 1)])
 def test_maxpool(dev, shape):
     from tg_hip import ops as O

@@ -235,9 +235,14 @@ def test_grouped_discriminator_passes(dev):
     for (k, a), (_k, b_) in zip(Ga.named_parameters(), Gb.named_parameters()):
         if a.grad is not None:
             assert torch.equal(a.grad, b_.grad), k
+    dgrads = dict(Db.named_parameters())
     for (k, a), (_k, b_) in zip(Da.named_parameters(), Db.named_parameters()):
         ga, gb_ = a.grad.double(), b_.grad.double()
-        assert (ga - gb_).abs().max().item() <= 2e-5 * gb_.abs().max().item() + 1e-9, k
+        # model.{2,5,8}.bias feed BatchNorm: analytically zero gradient, what is left is reduction-order noise (the grouped
+        # BatchNorm of the few-row layers sums in another order than the one-launch kernels of the separate passes) -- held to
+        # 1e-5 of the same conv's weight-gradient scale, like _zero_grad_atol
+        scale = dgrads[k[:-len("bias")] + "weight"].grad.abs().max().item() if k in ZERO_GRAD_BIASES else gb_.abs().max().item()
+        assert (ga - gb_).abs().max().item() <= (1e-5 if k in ZERO_GRAD_BIASES else 2e-5) * scale + 1e-9, k
     for (k, a), (_k, b_) in zip(Da.named_buffers(), Db.named_buffers()):
         assert torch.allclose(a.double(), b_.double(), rtol=1e-6, atol=1e-8), k
 

@@ -263,7 +263,7 @@ def main():
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh -> profiles/rNN_pmc_traffic.json);
         # it is not measurable from inside this process, so the driver's line carries null and names the committed profile
         traffic, traffic_src = None, None
-        for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             if os.path.exists(os.path.join(ROOT, "profiles", tname)):
                 traffic_src = "profiles/" + tname
                 break
@@ -340,7 +340,8 @@ def main():
                                      "exchange": "all-reduce(sum) of G and D gradient buckets, each launched when its last "
                                                  "gradient is enqueued; Adam per bucket after its wait; 1/world in the Adam kernel"}
                                     if (sync is not None and dist.is_initialized()) else None),
-                           "vgg_weights": "deterministic stand-in (ImageNet weights not fetchable offline; same FLOPs)"},
+                           "vgg_weights": "deterministic stand-in (ImageNet weights not fetchable offline; same FLOPs)",
+                           "vgg_trunk": "forward Winograd F(2x2,3x3), dgrads F(4x4,3x3) (DESIGN 2b)"},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if world > 1 or force_dp:

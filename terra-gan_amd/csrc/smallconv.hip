@@ -306,7 +306,9 @@ __global__ __launch_bounds__(256) void to1conv64_multi22_kernel(const IGemmMulti
 // pixel x 64 channel patch of a 4 x 32 output tile ONCE (52 KB; zero outside the image, mask pre-multiplied) and the nine
 // taps are 16-byte LDS reads of four neighbouring pixels = 1 KB contiguous per wave instruction (conflict-free).  Lane =
 // (pixel of a 4-pixel row segment, channel quad) and the 16-lane shuffle reduction are those of to1conv64_kernel.
-constexpr int T1_TH = 4, T1_TW = 32, T1_PH = T1_TH + 2, T1_PW = T1_TW + 2;
+// 4 x 16 output pixels per tile: 28 KB of LDS, five workgroups per CU.  (4 x 32 -- 52 KB, three per CU -- has 6 % less halo traffic
+// but too few loads in flight: `final` forward 87 -> 79 us, its weight gradient 77 -> 65 us with the narrower tile.)
+constexpr int T1_TH = 4, T1_TW = 16, T1_PH = T1_TH + 2, T1_PW = T1_TW + 2;
 __global__ __launch_bounds__(256) void to1conv64_lds_kernel(const IGemmParams p, int tiles_x, int tiles_y, int sy_min, int sx_min) {
     extern __shared__ __attribute__((aligned(16))) float sm[];      // [T1_PH][T1_PW][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -782,16 +784,25 @@ __global__ __launch_bounds__(256) void to1wgrad64_lds_kernel(const WgradParams p
         }
         if (threadIdx.x < T1_TH * T1_TW) dys[threadIdx.x] = dyv;
         __syncthreads();
-#pragma unroll 2
-        for (int seg = 0; seg < T1_TW / 4; ++seg) {
-            const int tx_o = 4 * seg + e;
-            const float d = dys[wave * T1_TW + tx_o];
-            const float* pb = sm + ((wave * T1_PW) + tx_o) * 64 + 4 * cq;
+        // lane (e, cq) takes FOUR consecutive pixels per segment of 16: the 3 x 6 patch pixels they share are read once (18 LDS
+        // reads for 36 tap updates instead of one read per update: 99 -> 77 us on `final`, 3.6 TB/s).  The same regrouping in the
+        // forward kernel changes nothing there (87 -> 90 us): it is not bound by its LDS reads; a persistent variant that
+        // requests the next tile's patch ahead of the compute phase is slower (137 us: 26 more live registers per thread)
+#pragma unroll 1
+        for (int seg = 0; seg < T1_TW / 16; ++seg) {
+            const int x0 = 16 * seg + 4 * e;
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dys + wave * T1_TW + x0);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* pr = sm + (((wave + ky) * T1_PW) + x0) * 64 + 4 * cq;
+                f32x4 X[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) X[c] = *reinterpret_cast<const f32x4*>(pr + c * 64);
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
-                    acc[ky * 3 + kx] += d * *reinterpret_cast<const f32x4*>(pb + (ky * T1_PW + kx) * 64);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ky * 3 + kx] += d[j] * X[j + kx];
+            }
         }
     }
     __syncthreads();
@@ -952,7 +963,7 @@ int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream
         TG_CHECK_LAUNCH("to1wgradw_kernel");
     } else if (to1_wgrad_lds_ok(p)) {
         const int tiles_x = cdiv(p.Wo, T1_TW), tiles_y = cdiv(p.Ho, T1_TH), ntiles = tiles_x * tiles_y * p.B;
-        nb = ntiles < 768 ? ntiles : 768;           // 3 resident workgroups per CU (52 KB of LDS each)
+        nb = ntiles < 768 ? ntiles : 768;           // three workgroups per CU (five would fit: 71 us against 65, more partials to reduce)
         const size_t lds = ((size_t)T1_PH * T1_PW * 64 + T1_TH * T1_TW) * sizeof(float);
         hipLaunchKernelGGL(to1wgrad64_lds_kernel, dim3(nb), dim3(256), lds, s, p, ws, tiles_x, tiles_y, ntiles);
         TG_CHECK_LAUNCH("to1wgrad64_lds_kernel");

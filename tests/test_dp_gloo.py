@@ -78,6 +78,23 @@ def _worker(rank, world, port, q):
         b.wait()
     assert sync._inflight == 0
     out3 = [p.grad.clone() * sync.grad_scale for p in m.parameters()]
+    # a gradient re-pointed AFTER its bucket went out (e.g. a caller re-assigning the unreduced tensors an engine returned) would
+    # make the optimiser read unreduced values scaled by 1/world: finish() refuses that pairing
+    for p in m.parameters():
+        p.grad = None
+    lb = sync.begin(m, "M")
+    for k in order:
+        lb.ready(k, torch.empty_like(dict(m.named_parameters())[k]).copy_(grads[k]))
+    victim = dict(m.named_parameters())[order[0]]
+    victim.grad = victim.grad.clone()
+    try:
+        lb.finish()
+        raise AssertionError("expected finish() to refuse a re-pointed gradient")
+    except RuntimeError as e:
+        assert "no longer aliases" in str(e)
+    for b in lb.launched:
+        b.wait()
+    assert sync._inflight == 0
     # a transport that completes synchronously (returns None) leaves nothing in flight; a raising one resets the count
     class SyncT(GradSync):
         def _all_reduce(self, flat):

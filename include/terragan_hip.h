@@ -98,6 +98,14 @@ int tg_conv_wprep_run(const void* items_dev, int n, tg_stream_t stream);
 int tg_conv_fwd_p(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* wprep,
                   const float* bias, const float* ratio, int act, float slope, float* y, float* ws,
                   size_t ws_bytes, tg_stream_t stream);
+/* tg_conv_fwd_p plus the 2x2 / stride-2 max-pool of its (activated) output: y [B][Ho][Wo][Cout] AND pool_y [B][Ho/2][Wo/2][Cout]
+ * (Ho, Wo even).  Replaces  features[i](x) -> ReLU -> MaxPool2d(2)  of the frozen VGG16 trunk
+ * (/root/reference/mvp_gan/src/utils/losses.py:31-34,79-90: torchvision vgg16().features[:16], layers 2-4 and 7-9) in one call:
+ * the stride-1 3x3 fp32 Winograd kernel writes the pooled tensor from its output transform (a 2x2 output tile is a pooling
+ * window); every other geometry runs tg_maxpool2_fwd on y.  Same values either way. */
+int tg_conv_fwd_pool(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* wprep,
+                     const float* bias, const float* ratio, int act, float slope, float* y, float* pool_y, float* ws,
+                     size_t ws_bytes, tg_stream_t stream);
 int tg_conv_dgrad_p(const TgConv* g, const float* dy, const float* w, const float* wprep, const float* in_mask,
                     const float* x_act, int act, float slope, float* dx, int accumulate, float* ws,
                     size_t ws_bytes, tg_stream_t stream);

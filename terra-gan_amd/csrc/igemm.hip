@@ -1327,9 +1327,30 @@ extern "C" size_t tg_conv_wprep_bytes(const TgConv* g, int mode) {
     return 0;
 }
 
+// (one host thread drives a stream's launches: the request travels to the launcher beside the parameters, like g_wprep_capture)
+static thread_local float* g_pool_request = nullptr;
+static thread_local int g_pool_fused = 0;
 static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, const float* w, float* wprep, int prep,
                          const float* bias, const float* ratio, int act, float slope, float* y, float* ws, size_t ws_bytes,
-                         tg_stream_t stream) {
+                         tg_stream_t stream, float* pool_y = nullptr) {
+    if (pool_y) {
+        // tg_conv_fwd_pool: the kernel that can write the pooled tensor from its output transform does (wino_pipe_kernel<.., POOL>);
+        // every other route runs the pool kernel on y -- the same values either way (a maximum has no rounding)
+        TG_REQUIRE(g && x && y && prep >= 0 && (g->Ho % 2) == 0 && (g->Wo % 2) == 0 && aligned16(pool_y),
+                   "tg_conv_fwd_pool: even output sizes and a 16-byte aligned pool_y expected");
+        int fused = 0;
+        if (!s2d_ok(g) && !wino22_fwd_geom_ok(g) && g->precision != TG_PREC_BF16) {
+            g_pool_request = pool_y;
+            g_pool_fused = 0;
+            const int rc1 = conv_fwd_impl(g, x, in_mask, w, wprep, prep, bias, ratio, act, slope, y, ws, ws_bytes, stream);
+            g_pool_request = nullptr;
+            if (rc1) return rc1;
+            fused = g_pool_fused;
+        } else if (int rc1 = conv_fwd_impl(g, x, in_mask, w, wprep, prep, bias, ratio, act, slope, y, ws, ws_bytes, stream)) {
+            return rc1;
+        }
+        return fused ? TG_OK : tg_maxpool2_fwd(y, g->B, g->Ho, g->Wo, g->Cout, pool_y, stream);
+    }
     int rc = check_conv(g, "tg_conv_fwd");
     if (rc) return rc;
     TG_REQUIRE(w && (prep < 0 || (x && y)), "tg_conv_fwd: null pointer");
@@ -1417,8 +1438,18 @@ static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, 
         }
     }
     if (prep < 0 && !p.wino_u) return TG_OK;              // this layer runs on the raw weights: nothing to prepare
+    p.pool_dst = g_pool_request;
     plan_splits(p, ws_floats);
-    return launch_igemm(p, (hipStream_t)stream, ws_floats);
+    rc = launch_igemm(p, (hipStream_t)stream, ws_floats);
+    if (g_pool_request) g_pool_fused = p.pool_done;
+    return rc;
+}
+extern "C" int tg_conv_fwd_pool(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* wprep,
+                                const float* bias, const float* ratio, int act, float slope, float* y, float* pool_y, float* ws,
+                                size_t ws_bytes, tg_stream_t stream) {
+    TG_REQUIRE(pool_y, "tg_conv_fwd_pool: null pointer");
+    return conv_fwd_impl(g, x, in_mask, w, const_cast<float*>(wprep), wprep ? 1 : 0, bias, ratio, act, slope, y, ws, ws_bytes, stream,
+                         pool_y);
 }
 extern "C" int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* bias,
                            const float* ratio, int act, float slope, float* y, float* ws, size_t ws_bytes,

@@ -32,6 +32,10 @@ struct IGemmParams {
     float* wino_u;
     int wino4;              // TG_PREC_F32_WINO4: Winograd F(4x4,3x3) where the geometry allows (wino44.inc)
     int wino_ready;         // wino_u already holds the transformed weights (prepared by tg_conv_wprep): skip the transform
+    // 2x2 / stride-2 max-pool of the (activated) output, written next to dst from the output transform (tg_conv_fwd_pool):
+    // [B][OH/2][OW/2][N].  A launcher that writes it sets pool_done; otherwise the caller runs the pool kernel on dst.
+    float* pool_dst;
+    int pool_done;
 };
 __device__ __forceinline__ float gate_factor(const IGemmParams& p, size_t idx) {
     const float gv = p.gate[idx];

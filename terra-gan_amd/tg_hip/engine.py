@@ -421,16 +421,22 @@ def vgg_forward(V, img, keep=True, wino4=None):
     force F(4x4,3x3) on (wherever the geometry allows) / off."""
     h = img.reshape(*img.shape, 1)
     steps = []
-    for item in VGG_TRUNK:
+    pooled = None
+    for i, item in enumerate(VGG_TRUNK):
         if item == "M":
-            o = O.maxpool2_fwd(h)
+            # (the conv below has written the pooled tensor with its own output where the sizes are even)
+            o = pooled if pooled is not None else O.maxpool2_fwd(h)
+            pooled = None
             if keep:
                 steps.append(NS(kind="M", x=h))
         else:
             w = V["0.folded"] if item == 0 else V[f"{item}.weight"]
             O.tag(f"vgg{item}.fwd")
-            o = O.conv_fwd(h, w, V[f"{item}.bias"], 3, 1, 1, act=O.ACT_RELU,
+            pool = i + 1 < len(VGG_TRUNK) and VGG_TRUNK[i + 1] == "M" and h.shape[1] % 2 == 0 and h.shape[2] % 2 == 0
+            o = O.conv_fwd(h, w, V[f"{item}.bias"], 3, 1, 1, act=O.ACT_RELU, pool=pool,
                            wino4=_vgg_wino4(w, h.shape[0], h.shape[1], h.shape[2], w.shape[0], wino4, VGG_WINO4_FWD))
+            if pool:
+                o, pooled = o
             if keep:
                 steps.append(NS(kind="C", w=w, x_shape=tuple(h.shape), a=o))
         h = o

@@ -52,6 +52,7 @@ SIGNATURES = {
     "tg_conv_wprep_item": (I, [CP, I, P, P, P]),
     "tg_conv_wprep_run": (I, [P, I, P]),
     "tg_conv_fwd_p": (I, [CP, P, P, P, P, P, P, I, F, P, P, SZ, P]),
+    "tg_conv_fwd_pool": (I, [CP, P, P, P, P, P, P, I, F, P, P, P, SZ, P]),
     "tg_conv_dgrad_p": (I, [CP, P, P, P, P, P, I, F, P, I, P, SZ, P]),
     "tg_conv_wgrad_ws_bytes": (SZ, [CP]),
     "tg_conv_wgrad": (I, [CP, P, P, P, P, P, P, SZ, P]),

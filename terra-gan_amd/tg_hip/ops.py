@@ -204,7 +204,9 @@ def _prepared(w, wv, g, mode):
     return ent[2]
 
 
-def conv_fwd(x, w, bias, k, stride, pad, in_mask=None, ratio=None, act=ACT_NONE, slope=0.0, wino4=False):
+def conv_fwd(x, w, bias, k, stride, pad, in_mask=None, ratio=None, act=ACT_NONE, slope=0.0, wino4=False, pool=False):
+    """pool=True: returns (y, maxpool2(y)) from one call (tg_conv_fwd_pool: the pooled tensor leaves the conv's output transform
+    where the kernel allows, the pool kernel runs on y otherwise)."""
     _chk(x, "x"); _chk(bias, "bias"); _chk(in_mask, "in_mask"); _chk(ratio, "ratio")
     wv = weight_view(w)
     _chk(wv, "weight")
@@ -214,6 +216,11 @@ def conv_fwd(x, w, bias, k, stride, pad, in_mask=None, ratio=None, act=ACT_NONE,
     lib = _lib()
     nb = lib.tg_conv_fwd_ws_bytes(C.byref(g))
     ws = workspace(nb)
+    if pool:
+        yp = empty(g.B, g.Ho // 2, g.Wo // 2, g.Cout, like=x)
+        L.check(lib.tg_conv_fwd_pool(C.byref(g), _p(x), _p(in_mask), _p(wv), _p(_prepared(w, wv, g, WPREP_FWD)), _p(bias), _p(ratio),
+                                     act, slope, _p(y), _p(yp), _p(ws), ws.numel() * 4, _stream()), "tg_conv_fwd_pool")
+        return y, yp
     L.check(lib.tg_conv_fwd_p(C.byref(g), _p(x), _p(in_mask), _p(wv), _p(_prepared(w, wv, g, WPREP_FWD)), _p(bias), _p(ratio),
                               act, slope, _p(y), _p(ws), ws.numel() * 4, _stream()), "tg_conv_fwd")
     return y

@@ -541,3 +541,70 @@ def test_wino44_prepared_weights_meet_a_launch_that_cannot_use_them(dev):
     for i in (0, 17, 63):
         d = (yb[4 * i:4 * i + 4] - ys).abs().max().item()
         assert d <= 2e-5 * max(1.0, ys.abs().max().item()), (i, d)
+
+
+# B, H, W, Cin, Cout, k, stride, pad -- tg_conv_fwd_pool: conv -> ReLU -> 2x2 max-pool in one call
+POOL_CASES = [
+    (8, 128, 128, 64, 64, 3, 1, 1),     # the cross-item pipeline, two items per workgroup: the pooled tensor leaves the output transform
+    (4, 96, 96, 64, 128, 3, 1, 1),      # two N tiles
+    (6, 80, 112, 24, 64, 3, 1, 1),      # ragged: 80 = 5 tiles, 112 = 7 tiles, three K steps
+    (3, 40, 24, 16, 64, 3, 1, 1),       # tiles half outside (40 = 2.5, 24 = 1.5): pooled rows / columns beyond the edge are dropped
+    (2, 20, 20, 16, 64, 3, 1, 0),       # pad 0: 18 x 18 output
+    (2, 16, 16, 1024, 128, 3, 1, 1),    # split-K: the pool kernel runs on y
+    (2, 32, 32, 64, 64, 4, 2, 1),       # F(2x2,2x2) layer: the pool kernel runs on y
+    (2, 32, 32, 1, 64, 3, 1, 1),        # 1-channel source (VGG conv1_1's kernel family)
+]
+
+
+@pytest.mark.parametrize("case", POOL_CASES)
+def test_conv_fwd_pool_equals_conv_then_pool(dev, case):
+    """The pooled tensor of tg_conv_fwd_pool and the convolution output next to it are bitwise what tg_conv_fwd_p followed by
+    tg_maxpool2_fwd give (a maximum rounds nothing) -- with the fixed item lists and with the work-stealing queues of DP runs."""
+    from tg_hip import lib as L
+    from tg_hip import ops as O
+    lib = L.load()
+    B, H, W, Cin, Cout, k, s_, p_ = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (k * Cin ** 0.5)).contiguous(memory_format=torch.channels_last).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    y0 = O.conv_fwd(x, w, b, k, s_, p_, act=O.ACT_RELU)
+    p0 = O.maxpool2_fwd(y0)
+    try:
+        for mode in (0, 2, 0):
+            L.check(lib.tg_set_work_stealing(mode), "tg_set_work_stealing")
+            y1, p1 = O.conv_fwd(x, w, b, k, s_, p_, act=O.ACT_RELU, pool=True)
+            assert p1.shape == p0.shape
+            assert torch.equal(y1, y0) and torch.equal(p1, p0), (mode, float((p1 - p0).abs().max()))
+    finally:
+        L.check(lib.tg_set_work_stealing(0), "tg_set_work_stealing")
+
+
+def test_conv_fwd_pool_is_fused_on_the_trunk_layers(dev, tmp_path):
+    """VGG conv1_2 / conv2_2 shapes: the pooled tensor is written by the Winograd launch itself (tag 4064) -- seen in its launch
+    record, whose algorithmic bytes then include the pooled tensor."""
+    import csv
+    from tg_hip import lib as L
+    from tg_hip import ops as O
+    lib = L.load()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(4, 64, 64, 64, generator=g).to(dev)
+    w = (torch.randn(128, 64, 3, 3, generator=g) * 0.05).contiguous(memory_format=torch.channels_last).to(dev)
+    b = torch.zeros(128).to(dev)
+    O.conv_fwd(x, w, b, 3, 1, 1, act=O.ACT_RELU, pool=True)          # (weights prepared outside the recorded region)
+    for kind in (0, 1, 2, 3):
+        lib.tg_prof_summary(kind, None, None, None, None)
+    lib.tg_prof_enable(1)
+    y, yp = O.conv_fwd(x, w, b, 3, 1, 1, act=O.ACT_RELU, pool=True)
+    torch.cuda.synchronize()
+    lib.tg_prof_enable(0)
+    path = str(tmp_path / "launches.csv")
+    assert lib.tg_prof_dump(path.encode()) == 0
+    rows = list(csv.DictReader(open(path)))
+    for kind in (0, 1, 2, 3):
+        lib.tg_prof_summary(kind, None, None, None, None)
+    assert [(r["kind"], r["cfg"]) for r in rows] == [("0", "4064")], rows
+    plain_mb = 4 * (x.numel() + y.numel() + w.numel() + y.numel() // 128) / 1e6
+    assert abs(float(rows[0]["alg_mb"]) - (plain_mb + 4 * yp.numel() / 1e6)) < 1e-2 * plain_mb, (rows[0]["alg_mb"], plain_mb)
+    assert torch.equal(yp, O.maxpool2_fwd(y))
+    assert float(yp.abs().sum()) > 0

@@ -106,6 +106,22 @@ int tg_conv_fwd_p(const TgConv* g, const float* x, const float* in_mask, const f
 int tg_conv_fwd_pool(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* wprep,
                      const float* bias, const float* ratio, int act, float slope, float* y, float* pool_y, float* ws,
                      size_t ws_bytes, tg_stream_t stream);
+/* BatchNorm + activation on load: the layer's input is act(BN(x)) -- x the PRE-BatchNorm output of the layer below, statistics
+ * and affine parameters in `bn` -- and that tensor is never written.  For `final` (generator.py:29,56: Conv2d(64, 1, 3, 1, 1) over
+ * dec1's ReLU(BN(.)) output, pconv.py:43-48): saves dec1's BatchNorm-apply pass (one read + one write of the widest activation).
+ * Same rounding sequence as tg_bn_act_fwd, so results equal the two-call form bit for bit.  tg_conv_bnin_supported(g, wgrad)
+ * says whether the geometry has the kernel (64 -> 1 channels, 3x3, stride 1, pad 1, W % 4 == 0, at least 4 x 16 pixels);
+ * the two calls fail otherwise (the caller then materialises the activation with tg_bn_act_fwd). */
+typedef struct TgBnAct {
+    const float *mean, *rstd, *gamma, *beta;   /* [Cin] each */
+    int32_t act;                               /* TG_ACT_* */
+    float slope;
+} TgBnAct;
+int tg_conv_bnin_supported(const TgConv* g, int wgrad);
+int tg_conv_fwd_bnin(const TgConv* g, const float* x, const TgBnAct* bn, const float* w, const float* bias, int act,
+                     float slope, float* y, float* ws, size_t ws_bytes, tg_stream_t stream);
+int tg_conv_wgrad_bnin(const TgConv* g, const float* x, const TgBnAct* bn, const float* dy, float* dw, float* db, float* ws,
+                       size_t ws_bytes, tg_stream_t stream);
 int tg_conv_dgrad_p(const TgConv* g, const float* dy, const float* w, const float* wprep, const float* in_mask,
                     const float* x_act, int act, float slope, float* dx, int accumulate, float* ws,
                     size_t ws_bytes, tg_stream_t stream);
@@ -245,6 +261,10 @@ int tg_pixel_losses(const float* pred, const float* target, const float* mask,
 size_t tg_reduce_ws_bytes(int64_t n);
 int tg_l1_mean(const float* a, const float* b, int64_t n, float coef, const float* gscale,
                float* out1, float* da, float* ws, size_t ws_bytes, tg_stream_t stream);
+/* The same with `a` a ReLU OUTPUT and the gradient taken in front of that ReLU: da = (a > 0) ? coef*g*sign(a-b)/n : 0 -- the
+ * perceptual term's L1 over relu3_3 features (losses.py:86-89) and the backward of features[15] = ReLU(inplace) in one pass. */
+int tg_l1_mean_relu(const float* a, const float* b, int64_t n, float coef, const float* gscale, float* out1, float* da,
+                    float* ws, size_t ws_bytes, tg_stream_t stream);
 
 /* nn.BCEWithLogitsLoss (mean) against the constant `target` (train.py:115,203,215-216):
  * out[0] = loss; if dz != NULL: dz = coef * (*gscale) * (sigmoid(z)-target)/n. */

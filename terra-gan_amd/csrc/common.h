@@ -53,6 +53,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// one rounding sequence for BatchNorm's affine map wherever it is applied (bn_act_fwd kernels, BN-on-load staging): sub, mul, fma
+__device__ __forceinline__ float bn_affine(float v, float m, float r, float g, float b) {
+    return __fmaf_rn(__fmul_rn(__fsub_rn(v, m), r), g, b);
+}
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     if (act == TG_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == TG_ACT_LEAKY) return v > 0.f ? v : v * slope;

@@ -1330,6 +1330,7 @@ extern "C" size_t tg_conv_wprep_bytes(const TgConv* g, int mode) {
 // (one host thread drives a stream's launches: the request travels to the launcher beside the parameters, like g_wprep_capture)
 static thread_local float* g_pool_request = nullptr;
 static thread_local int g_pool_fused = 0;
+static thread_local const BnIn* g_bnin_request = nullptr;      // tg_conv_fwd_bnin
 static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, const float* w, float* wprep, int prep,
                          const float* bias, const float* ratio, int act, float slope, float* y, float* ws, size_t ws_bytes,
                          tg_stream_t stream, float* pool_y = nullptr) {
@@ -1439,6 +1440,10 @@ static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, 
     }
     if (prep < 0 && !p.wino_u) return TG_OK;              // this layer runs on the raw weights: nothing to prepare
     p.pool_dst = g_pool_request;
+    if (g_bnin_request) {
+        p.in_bn = *g_bnin_request;
+        TG_REQUIRE(smallconv_bnin_fwd_ok(p), "tg_conv_fwd_bnin: geometry not supported (ask tg_conv_bnin_supported first)");
+    }
     plan_splits(p, ws_floats);
     rc = launch_igemm(p, (hipStream_t)stream, ws_floats);
     if (g_pool_request) g_pool_fused = p.pool_done;
@@ -1450,6 +1455,34 @@ extern "C" int tg_conv_fwd_pool(const TgConv* g, const float* x, const float* in
     TG_REQUIRE(pool_y, "tg_conv_fwd_pool: null pointer");
     return conv_fwd_impl(g, x, in_mask, w, const_cast<float*>(wprep), wprep ? 1 : 0, bias, ratio, act, slope, y, ws, ws_bytes, stream,
                          pool_y);
+}
+static bool bnin_geom_ok(const TgConv* g) {
+    return g && g->Cout == 1 && g->Cin == 64 && g->k == 3 && g->stride == 1 && g->pad == 1 && (g->Wo % 4) == 0;
+}
+static BnIn bnin_of(const TgBnAct* bn) { return BnIn{bn->mean, bn->rstd, bn->gamma, bn->beta, bn->act, bn->slope}; }
+extern "C" int tg_conv_bnin_supported(const TgConv* g, int wgrad) {
+    if (!bnin_geom_ok(g)) return 0;
+    if (wgrad) {
+        WgradParams p = {};
+        p.B = g->B; p.H = g->H; p.W = g->W; p.C = g->Cin; p.Ho = g->Ho; p.Wo = g->Wo; p.Cout = g->Cout;
+        p.k = g->k; p.stride = g->stride; p.pad = g->pad;
+        p.Mpix = g->B * g->Ho * g->Wo; p.Ktot = g->k * g->k * g->Cin;
+        return smallconv_wgrad_applies(p) && smallconv_bnin_wgrad_ok(p) ? 1 : 0;
+    }
+    IGemmParams p = {};
+    p.B = g->B; p.IH = g->H; p.IW = g->W; p.C = g->Cin; p.OH = g->Ho; p.OW = g->Wo; p.N = g->Cout; p.M = g->B * g->Ho * g->Wo;
+    p.TH = g->k; p.TW = g->k; p.ss = g->stride; p.tstep = 1; p.sy0 = -g->pad; p.sx0 = -g->pad;
+    return smallconv_bnin_fwd_ok(p) ? 1 : 0;
+}
+extern "C" int tg_conv_fwd_bnin(const TgConv* g, const float* x, const TgBnAct* bn, const float* w, const float* bias, int act,
+                                float slope, float* y, float* ws, size_t ws_bytes, tg_stream_t stream) {
+    TG_REQUIRE(bn && bn->mean && bn->rstd && bn->gamma && bn->beta, "tg_conv_fwd_bnin: null pointer");
+    TG_REQUIRE(tg_conv_bnin_supported(g, 0), "tg_conv_fwd_bnin: geometry not supported (ask tg_conv_bnin_supported first)");
+    const BnIn b = bnin_of(bn);
+    g_bnin_request = &b;
+    const int rc = conv_fwd_impl(g, x, nullptr, w, nullptr, 0, bias, nullptr, act, slope, y, ws, ws_bytes, stream);
+    g_bnin_request = nullptr;
+    return rc;
 }
 extern "C" int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* bias,
                            const float* ratio, int act, float slope, float* y, float* ws, size_t ws_bytes,
@@ -2245,8 +2278,21 @@ extern "C" size_t tg_conv_wgrad_ws_bytes(const TgConv* g) {
     return (slabs + tg_colsum_ws_floats((int64_t)g->B * g->Ho * g->Wo, g->Cout)) * sizeof(float);
 }
 
+static int conv_wgrad_impl(const TgConv* g, const float* x, const float* in_mask, const float* dy, float* dw, float* db, float* ws,
+                           size_t ws_bytes, tg_stream_t stream, const BnIn* in_bn);
 extern "C" int tg_conv_wgrad(const TgConv* g, const float* x, const float* in_mask, const float* dy, float* dw,
                              float* db, float* ws, size_t ws_bytes, tg_stream_t stream) {
+    return conv_wgrad_impl(g, x, in_mask, dy, dw, db, ws, ws_bytes, stream, nullptr);
+}
+extern "C" int tg_conv_wgrad_bnin(const TgConv* g, const float* x, const TgBnAct* bn, const float* dy, float* dw, float* db, float* ws,
+                                  size_t ws_bytes, tg_stream_t stream) {
+    TG_REQUIRE(bn && bn->mean && bn->rstd && bn->gamma && bn->beta, "tg_conv_wgrad_bnin: null pointer");
+    TG_REQUIRE(tg_conv_bnin_supported(g, 1), "tg_conv_wgrad_bnin: geometry not supported (ask tg_conv_bnin_supported first)");
+    const BnIn b = bnin_of(bn);
+    return conv_wgrad_impl(g, x, nullptr, dy, dw, db, ws, ws_bytes, stream, &b);
+}
+static int conv_wgrad_impl(const TgConv* g, const float* x, const float* in_mask, const float* dy, float* dw, float* db, float* ws,
+                           size_t ws_bytes, tg_stream_t stream, const BnIn* in_bn) {
     int rc = check_conv(g, "tg_conv_wgrad");
     if (rc) return rc;
     TG_REQUIRE(x && dy && dw && ws, "tg_conv_wgrad: null pointer");
@@ -2260,6 +2306,10 @@ extern "C" int tg_conv_wgrad(const TgConv* g, const float* x, const float* in_ma
     p.k = g->k; p.stride = g->stride; p.pad = g->pad;
     p.Mpix = g->B * g->Ho * g->Wo; p.Ktot = g->k * g->k * g->Cin;
     wgrad_plan(g, &p.splits, &p.steps_per_split, &p.T);
+    if (in_bn) {
+        p.in_bn = *in_bn;
+        TG_REQUIRE(smallconv_wgrad_applies(p) && smallconv_bnin_wgrad_ok(p), "tg_conv_wgrad_bnin: geometry not supported");
+    }
     if (smallconv_wgrad_applies(p)) {
         {
             const double by = 4.0 * ((double)p.B * p.H * p.W * p.C + (double)p.Mpix * p.Cout + (double)p.Cout * p.Ktot);

@@ -2,6 +2,13 @@
 #pragma once
 #include "common.h"
 
+// BatchNorm + activation applied to the SOURCE tensor as it is staged (tg_conv_fwd_bnin / tg_conv_wgrad_bnin): the layer's input
+// is act(BN(src)) without that tensor ever being written.  mean == nullptr: none.
+struct BnIn {
+    const float *mean, *rstd, *gamma, *beta;
+    int act;
+    float slope;
+};
 struct IGemmParams {
     const float* src;       // A source, NHWC [B][IH][IW][C]
     const float* amask;     // optional [B][IH][IW]: A row scale at the SOURCE pixel (x (.) mask)
@@ -36,6 +43,7 @@ struct IGemmParams {
     // [B][OH/2][OW/2][N].  A launcher that writes it sets pool_done; otherwise the caller runs the pool kernel on dst.
     float* pool_dst;
     int pool_done;
+    BnIn in_bn;             // (the 64 -> 1 channel LDS-patch kernel only: `final`, smallconv.hip)
 };
 __device__ __forceinline__ float gate_factor(const IGemmParams& p, size_t idx) {
     const float gv = p.gate[idx];
@@ -56,6 +64,7 @@ struct WgradParams {
     int Mpix, Ktot, T, splits, steps_per_split;
     int nx, ny;   // N' tiles, Cout tiles (grid is launched flat: nx*ny*splits workgroups)
     int rowseg;   // Wo % 32 == 0: every 32-pixel K step lies inside one output row (cheap gather addressing)
+    BnIn in_bn;   // (to1wgrad64_lds_kernel only)
 };
 
 // smallconv.hip: bandwidth-bound special cases that would waste >95% of an MFMA tile
@@ -64,5 +73,7 @@ int smallconv_fwd_launch(const IGemmParams& p, hipStream_t s);
 bool smallconv_to1_multi_applies(const IGemmParams* cls, int ncls);   // 64 -> 1 channel, the four 2x2-tap classes of a 4x4 stride-2 dgrad
 int smallconv_to1_multi_launch(const IGemmParams* cls, int ncls, hipStream_t s);
 bool smallconv_wgrad_applies(const WgradParams& p);
+bool smallconv_bnin_fwd_ok(const IGemmParams& p);             // launches that can take IGemmParams::in_bn / WgradParams::in_bn
+bool smallconv_bnin_wgrad_ok(const WgradParams& p);
 size_t smallconv_wgrad_ws_floats(const WgradParams& p);
 int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream_t s);

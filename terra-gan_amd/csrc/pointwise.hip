@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd4_kernel(const float* __restric
             const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * C + c0);
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = apply_act((v[e] - mv[e]) * rv[e] * gv[e] + bv[e], act, slope);
+            for (int e = 0; e < 4; ++e) o[e] = apply_act(bn_affine(v[e], mv[e], rv[e], gv[e], bv[e]), act, slope);
             *reinterpret_cast<f32x4*>(out + r * C + c0) = o;
         }
     }
@@ -1480,15 +1480,18 @@ extern "C" int tg_pixel_losses(const float* pred, const float* target, const flo
     return TG_OK;
 }
 // ---- mean |a-b| (+ gradient) -----------------------------------------------------------------------------
+// RELU_GATE: `a` is a ReLU output and the gradient wanted is the one in front of that ReLU: da = (a > 0) * d mean|a-b| / da
+template <bool RELU_GATE>
 __global__ __launch_bounds__(256) void l1_mean_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
                                                       float coef, const float* __restrict__ gscale, float* __restrict__ da,
                                                       double* __restrict__ partial) {
     double q[1] = {0};
     const float k = da ? coef * (gscale ? *gscale : 1.f) / (float)n : 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float d = a[i] - b[i];
+        const float av = a[i];
+        const float d = av - b[i];
         q[0] += (double)fabsf(d);
-        if (da) da[i] = k * sgn(d);
+        if (da) da[i] = (!RELU_GATE || av > 0.f) ? k * sgn(d) : 0.f;
     }
     block_reduce_store<1>(q, partial);
 }
@@ -1499,17 +1502,26 @@ __global__ void mean_final_kernel(const double* __restrict__ partial, int nblock
     s = wave_sum_d(s);
     if (threadIdx.x == 0) out[0] = (float)(s * inv_n);
 }
-extern "C" int tg_l1_mean(const float* a, const float* b, int64_t n, float coef, const float* gscale, float* out1, float* da,
-                          float* ws, size_t ws_bytes, tg_stream_t stream) {
+static int l1_mean_launch(const float* a, const float* b, int64_t n, float coef, const float* gscale, float* out1, float* da,
+                          float* ws, size_t ws_bytes, tg_stream_t stream, bool relu_gate) {
     TG_REQUIRE(a && b && out1 && ws && n > 0, "tg_l1_mean: bad arguments");
     TG_REQUIRE(ws_bytes >= tg_reduce_ws_bytes(n), "tg_l1_mean: workspace too small");
     const int grid = red_grid(n);
     double* partial = reinterpret_cast<double*>(ws);
-    hipLaunchKernelGGL(l1_mean_kernel, dim3(grid), dim3(256), 0, S(stream), a, b, n, coef, gscale, da, partial);
+    if (relu_gate) hipLaunchKernelGGL(l1_mean_kernel<true>, dim3(grid), dim3(256), 0, S(stream), a, b, n, coef, gscale, da, partial);
+    else hipLaunchKernelGGL(l1_mean_kernel<false>, dim3(grid), dim3(256), 0, S(stream), a, b, n, coef, gscale, da, partial);
     TG_CHECK_LAUNCH("l1_mean_kernel");
     hipLaunchKernelGGL(mean_final_kernel, dim3(1), dim3(64), 0, S(stream), partial, grid, 1.0 / (double)n, out1);
     TG_CHECK_LAUNCH("mean_final_kernel");
     return TG_OK;
+}
+extern "C" int tg_l1_mean(const float* a, const float* b, int64_t n, float coef, const float* gscale, float* out1, float* da,
+                          float* ws, size_t ws_bytes, tg_stream_t stream) {
+    return l1_mean_launch(a, b, n, coef, gscale, out1, da, ws, ws_bytes, stream, false);
+}
+extern "C" int tg_l1_mean_relu(const float* a, const float* b, int64_t n, float coef, const float* gscale, float* out1, float* da,
+                               float* ws, size_t ws_bytes, tg_stream_t stream) {
+    return l1_mean_launch(a, b, n, coef, gscale, out1, da, ws, ws_bytes, stream, true);
 }
 
 // ---- BCE with logits, constant target -------------------------------------------------------------------
@@ -1775,7 +1787,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd4_grouped_kernel(const float* _
             const f32x4 v = *reinterpret_cast<const f32x4*>(yg + r * C + c0);
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = apply_act((v[e] - mv[e]) * rv[e] * gv[e] + bv[e], act, slope);
+            for (int e = 0; e < 4; ++e) o[e] = apply_act(bn_affine(v[e], mv[e], rv[e], gv[e], bv[e]), act, slope);
             *reinterpret_cast<f32x4*>(og + r * C + c0) = o;
         }
     }

@@ -309,6 +309,19 @@ __global__ __launch_bounds__(256) void to1conv64_multi22_kernel(const IGemmMulti
 // 4 x 16 output pixels per tile: 28 KB of LDS, five workgroups per CU.  (4 x 32 -- 52 KB, three per CU -- has 6 % less halo traffic
 // but too few loads in flight: `final` forward 87 -> 79 us, its weight gradient 77 -> 65 us with the narrower tile.)
 constexpr int T1_TH = 4, T1_TW = 16, T1_PH = T1_TH + 2, T1_PW = T1_TW + 2;
+// BN-on-load: a thread's staging slots all belong to ONE channel quad (256 % 16 == 0), its constants are fetched once
+template <int NIT>
+__device__ __forceinline__ void bn_in_stage(const BnIn& bn, f32x4 (&v)[NIT], int c0) {
+    const f32x4 mv = *reinterpret_cast<const f32x4*>(bn.mean + c0), rv = *reinterpret_cast<const f32x4*>(bn.rstd + c0);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(bn.gamma + c0), bv = *reinterpret_cast<const f32x4*>(bn.beta + c0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[it][k] = apply_act(bn_affine(v[it][k], mv[k], rv[k], gv[k], bv[k]), bn.act, bn.slope);
+}
+// BNIN: the source is act(BN(src)) (IGemmParams::in_bn, no source mask): its own instantiation, with the in-range flags as a bit
+// mask instead of seven floats -- the sixteen per-channel constants then fit without costing a resident wave.
+template <bool BNIN>
 __global__ __launch_bounds__(256) void to1conv64_lds_kernel(const IGemmParams p, int tiles_x, int tiles_y, int sy_min, int sx_min) {
     extern __shared__ __attribute__((aligned(16))) float sm[];      // [T1_PH][T1_PW][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -325,7 +338,8 @@ __global__ __launch_bounds__(256) void to1conv64_lds_kernel(const IGemmParams p,
     // stage the patch: thread = (pixel slot, channel quad); all 13 loads of a thread in flight together
     constexpr int NSLOT = T1_PH * T1_PW * 16, NIT = (NSLOT + 255) / 256;
     f32x4 v[NIT];
-    float f[NIT];
+    float f[BNIN ? 1 : NIT];
+    uint32_t inbits = 0;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int slot = threadIdx.x + 256 * it, pp = slot >> 4;
@@ -334,14 +348,22 @@ __global__ __launch_bounds__(256) void to1conv64_lds_kernel(const IGemmParams p,
         const bool in = slot < NSLOT && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
         const size_t pix = in ? ((size_t)b * p.IH + iy) * p.IW + ix : 0;
         v[it] = *reinterpret_cast<const f32x4*>(p.src + pix * 64 + 4 * (slot & 15));
-        f[it] = !in ? 0.f : (p.amask ? p.amask[pix] : 1.f);
+        if constexpr (BNIN) inbits |= (in ? 1u : 0u) << it;
+        else f[it] = !in ? 0.f : (p.amask ? p.amask[pix] : 1.f);
     }
+    if constexpr (BNIN) bn_in_stage<NIT>(p.in_bn, v, 4 * (threadIdx.x & 15));
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int slot = threadIdx.x + 256 * it;
-        f32x4 o = v[it] * f[it];
+        f32x4 o;
+        if constexpr (BNIN) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = f[it] != 0.f ? o[k] : 0.f;
+            for (int k = 0; k < 4; ++k) o[k] = (inbits >> it) & 1u ? v[it][k] : 0.f;
+        } else {
+            o = v[it] * f[it];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = f[it] != 0.f ? o[k] : 0.f;
+        }
         if (slot < NSLOT) *reinterpret_cast<f32x4*>(sm + 4 * slot) = o;
     }
     __syncthreads();
@@ -449,6 +471,14 @@ bool smallconv_fwd_applies(const IGemmParams& p) {
     return false;
 }
 
+static bool to1_fwd_lds_ok(const IGemmParams& p) {
+    static const bool no_lds = getenv("TG_NO_TO1LDS") != nullptr;
+    return !no_lds && p.TH == 3 && p.TW == 3 && p.ss == 1 && (p.tstep == 1 || p.tstep == -1) && p.OH >= T1_TH && p.OW >= T1_TW;
+}
+bool smallconv_bnin_fwd_ok(const IGemmParams& p) {
+    return smallconv_fwd_applies(p) && p.N == 1 && p.C == 64 && !to1w_ok(p) && to1_fwd_lds_ok(p) && !p.amask;
+}
+
 bool smallconv_to1_multi_applies(const IGemmParams* cls, int ncls) {
     if (getenv("TG_NO_SMALLCONV") || getenv("TG_NO_TO1_MULTI") || ncls != 4) return false;
     for (int i = 0; i < ncls; ++i) {
@@ -476,6 +506,7 @@ int smallconv_to1_multi_launch(const IGemmParams* cls, int ncls, hipStream_t s) 
     }
 
 int smallconv_fwd_launch(const IGemmParams& p, hipStream_t s) {
+    TG_REQUIRE(!p.in_bn.mean || smallconv_bnin_fwd_ok(p), "smallconv: BatchNorm-on-load is not available for this geometry");
     if (p.C == 1) {
         C1Geom q;
         q.tiles_x = cdiv(p.OW, C1_T);
@@ -516,13 +547,13 @@ int smallconv_fwd_launch(const IGemmParams& p, hipStream_t s) {
         TG_CHECK_LAUNCH("to1convw_kernel");
         return TG_OK;
     }
-    static const bool no_lds = getenv("TG_NO_TO1LDS") != nullptr;
-    if (!no_lds && p.TH == 3 && p.TW == 3 && p.ss == 1 && (p.tstep == 1 || p.tstep == -1) && p.OH >= T1_TH && p.OW >= T1_TW) {
+    if (to1_fwd_lds_ok(p)) {
         const int tiles_x = cdiv(p.OW, T1_TW), tiles_y = cdiv(p.OH, T1_TH);
         const int sy_b = p.sy0 + 2 * p.tstep, sx_b = p.sx0 + 2 * p.tstep;
         const int sy_min = p.sy0 < sy_b ? p.sy0 : sy_b, sx_min = p.sx0 < sx_b ? p.sx0 : sx_b;
         const size_t lds = (size_t)T1_PH * T1_PW * 64 * sizeof(float);
-        hipLaunchKernelGGL(to1conv64_lds_kernel, dim3(tiles_x * tiles_y * p.B), dim3(256), lds, s, p, tiles_x, tiles_y, sy_min, sx_min);
+        if (p.in_bn.mean) hipLaunchKernelGGL(to1conv64_lds_kernel<true>, dim3(tiles_x * tiles_y * p.B), dim3(256), lds, s, p, tiles_x, tiles_y, sy_min, sx_min);
+        else hipLaunchKernelGGL(to1conv64_lds_kernel<false>, dim3(tiles_x * tiles_y * p.B), dim3(256), lds, s, p, tiles_x, tiles_y, sy_min, sx_min);
         TG_CHECK_LAUNCH("to1conv64_lds_kernel");
         return TG_OK;
     }
@@ -739,6 +770,7 @@ __global__ __launch_bounds__(256) void to1wgrad64_kernel(const WgradParams p, fl
 
 // Cout == 1, C == 64, 3x3 stride 1: the weight gradient through the same LDS patch (see to1conv64_lds_kernel).  Persistent
 // workgroups walk 4 x 32-pixel tiles and keep the 9 x 4-channel accumulators in registers; partial[block][tap][c].
+template <bool BNIN>
 __global__ __launch_bounds__(256) void to1wgrad64_lds_kernel(const WgradParams p, float* __restrict__ partial, int tiles_x, int tiles_y,
                                                              int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float sm[];      // [T1_PH][T1_PW][64] + dy tile [T1_TH][T1_TW]
@@ -757,7 +789,8 @@ __global__ __launch_bounds__(256) void to1wgrad64_lds_kernel(const WgradParams p
         const int tyi = tile % tiles_y, b = tile / tiles_y;
         const int oy0 = tyi * T1_TH, ox0 = txi * T1_TW;
         f32x4 v[NIT];
-        float f[NIT];
+        float f[BNIN ? 1 : NIT];
+        uint32_t inbits = 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int slot = threadIdx.x + 256 * it, pp = slot >> 4;
@@ -766,20 +799,28 @@ __global__ __launch_bounds__(256) void to1wgrad64_lds_kernel(const WgradParams p
             const bool in = slot < NSLOT && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             const size_t pix = in ? ((size_t)b * p.H + iy) * p.W + ix : 0;
             v[it] = *reinterpret_cast<const f32x4*>(p.x + pix * 64 + 4 * (slot & 15));
-            f[it] = !in ? 0.f : (p.amask ? p.amask[pix] : 1.f);
+            if constexpr (BNIN) inbits |= (in ? 1u : 0u) << it;
+            else f[it] = !in ? 0.f : (p.amask ? p.amask[pix] : 1.f);
         }
         float dyv = 0.f;
         if (threadIdx.x < T1_TH * T1_TW) {
             const int oy = oy0 + threadIdx.x / T1_TW, ox = ox0 + threadIdx.x % T1_TW;
             if (oy < p.Ho && ox < p.Wo) dyv = p.dy[((size_t)b * p.Ho + oy) * p.Wo + ox];
         }
+        if constexpr (BNIN) bn_in_stage<NIT>(p.in_bn, v, 4 * (threadIdx.x & 15));
         __syncthreads();                     // the previous tile's readers are done
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int slot = threadIdx.x + 256 * it;
-            f32x4 o = v[it] * f[it];
+            f32x4 o;
+            if constexpr (BNIN) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = f[it] != 0.f ? o[k] : 0.f;
+                for (int k = 0; k < 4; ++k) o[k] = (inbits >> it) & 1u ? v[it][k] : 0.f;
+            } else {
+                o = v[it] * f[it];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = f[it] != 0.f ? o[k] : 0.f;
+            }
             if (slot < NSLOT) *reinterpret_cast<f32x4*>(sm + 4 * slot) = o;
         }
         if (threadIdx.x < T1_TH * T1_TW) dys[threadIdx.x] = dyv;
@@ -917,6 +958,7 @@ static bool to1_wgrad_lds_ok(const WgradParams& p) {
     static const bool off = getenv("TG_NO_TO1LDS") != nullptr;
     return !off && p.Cout == 1 && p.C == 64 && p.k == 3 && p.stride == 1 && p.pad == 1 && p.Ho >= T1_TH && p.Wo >= T1_TW;
 }
+bool smallconv_bnin_wgrad_ok(const WgradParams& p) { return !getenv("TG_NO_SMALLCONV") && (p.Wo % 4) == 0 && to1_wgrad_lds_ok(p) && !p.amask; }
 bool smallconv_wgrad_applies(const WgradParams& p) {
     if (getenv("TG_NO_SMALLCONV")) return false;
     // Cin == 1 weight gradients measured faster on the MFMA wgrad kernel's scalar-gather path (0.11 vs 0.27 ms for
@@ -932,6 +974,7 @@ size_t smallconv_wgrad_ws_floats(const WgradParams& p) {
     return (size_t)blocks * p.Cout * p.k * p.k * p.C + 64;
 }
 int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream_t s) {
+    TG_REQUIRE(!p.in_bn.mean || smallconv_bnin_wgrad_ok(p), "smallconv: BatchNorm-on-load is not available for this geometry");
     int nb;
     if (p.C == 1) {
         C1Geom q;
@@ -965,7 +1008,8 @@ int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream
         const int tiles_x = cdiv(p.Wo, T1_TW), tiles_y = cdiv(p.Ho, T1_TH), ntiles = tiles_x * tiles_y * p.B;
         nb = ntiles < 768 ? ntiles : 768;           // three workgroups per CU (five would fit: 71 us against 65, more partials to reduce)
         const size_t lds = ((size_t)T1_PH * T1_PW * 64 + T1_TH * T1_TW) * sizeof(float);
-        hipLaunchKernelGGL(to1wgrad64_lds_kernel, dim3(nb), dim3(256), lds, s, p, ws, tiles_x, tiles_y, ntiles);
+        if (p.in_bn.mean) hipLaunchKernelGGL(to1wgrad64_lds_kernel<true>, dim3(nb), dim3(256), lds, s, p, ws, tiles_x, tiles_y, ntiles);
+        else hipLaunchKernelGGL(to1wgrad64_lds_kernel<false>, dim3(nb), dim3(256), lds, s, p, ws, tiles_x, tiles_y, ntiles);
         TG_CHECK_LAUNCH("to1wgrad64_lds_kernel");
     } else {
         const int quads = p.Mpix / 4;

@@ -146,11 +146,12 @@ def criterion_forward(crit, pred, target, mask, want_grad, gscale=None, l1_weigh
             both[B:].copy_(target)
         feats, vctx = E.vgg_forward(V, both, keep=want_grad)
         fp, ft = feats[:B], feats[B:]
-        perc, dfeat = O.l1_mean(fp, ft, w_p * scale, gscale=gscale, want_grad=want_grad)
+        # (the features are ReLU outputs: the L1 gradient comes out already gated by features[15])
+        perc, dfeat = O.l1_mean(fp, ft, w_p * scale, gscale=gscale, want_grad=want_grad, relu_gate=True)
         parts["perc"] = perc
         total = O.lincomb(total, 1.0, perc, w_p * scale)
         if want_grad:
-            dperc = E.vgg_backward(vctx, dfeat, nb=B)
+            dperc = E.vgg_backward(vctx, dfeat, nb=B, gated=True)
             O.axpby_(dperc, 1.0, 1.0, dp)
     return total, parts, dp
 

@@ -108,20 +108,22 @@ def join_side():
 # --------------------------------------------------------------------------------------------------
 # partial-conv layer (conv -> *ratio -> BN -> ReLU)
 # --------------------------------------------------------------------------------------------------
-def _pconv_fwd(P, name, k, s, p, x, in_mask, ratio, training, premasked=False):
+def _pconv_fwd(P, name, k, s, p, x, in_mask, ratio, training, premasked=False, defer_act=False):
     """premasked: x already holds input*mask (the decoder concat is written that way), so the conv and its
-    wgrad skip the mask prologue; dgrad still applies the mask."""
+    wgrad skip the mask prologue; dgrad still applies the mask.
+    defer_act: ReLU(BN(y)) is NOT written (returned activation = None): the layer's one consumer applies it while loading y
+    (dec1 -> `final`: O.conv_fwd_bnin / conv_wgrad(in_bn=...), with _bn_in(P, ctx))."""
     O.tag(f"{name}.fwd")
     y = O.conv_fwd(x, P[f"{name}.input_conv.weight"], P[f"{name}.input_conv.bias"].detach(), k, s, p,
                    in_mask=None if premasked else in_mask, ratio=ratio)
     if training:
         mean, rstd, a = O.bn_fwd(y, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU, 0.0, P[f"{name}.bn.running_mean"],
-                                 P[f"{name}.bn.running_var"], P[f"{name}.bn.num_batches_tracked"])
+                                 P[f"{name}.bn.running_var"], P[f"{name}.bn.num_batches_tracked"], apply=not defer_act)
     else:
         mean, rstd = O.bn_eval_stats(P[f"{name}.bn.running_mean"], P[f"{name}.bn.running_var"])
-        a = O.bn_act_fwd(y, mean, rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU)
+        a = None if defer_act else O.bn_act_fwd(y, mean, rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU)
     if PROBE is not None:
-        PROBE("fwd", name, a)
+        PROBE("fwd", name, a if a is not None else O.bn_act_fwd(y, mean, rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU))
     return a, NS(name=name, k=k, s=s, p=p, x=x, in_mask=in_mask, ratio=ratio, y=y, mean=mean, rstd=rstd,
                  premasked=premasked)
 
@@ -182,18 +184,24 @@ def generator_forward(P, x, mask, training=True, checkpoint=False, out=None):
         e.append(a)
         enc_ctx.append(c)
     d, dec_ctx = e[7], []
+    fshape = (B, H, W, G_DEC[6][2])
+    bnin_final = BNIN_FINAL and O.conv_bnin_supported(fshape, 1, 3, 1, 1) and O.conv_bnin_supported(fshape, 1, 3, 1, 1, wgrad=True)
     for i, (name, _ci, _co, k, s, p) in enumerate(G_DEC):
         skip = e[6 - i] if i < 6 else None
         Hs, Ws = (skip.shape[1], skip.shape[2]) if skip is not None else (H, W)
         up_shape = tuple(d.shape)
         cat = O.upcat_fwd(d, skip, Hs, Ws, out_mask=dmasks[i])       # = merged_feature * merged_mask
-        d, c = _pconv_fwd(P, name, k, s, p, cat, dmasks[i], dr[i], training, premasked=True)
+        defer = i == 6 and bnin_final
+        d, c = _pconv_fwd(P, name, k, s, p, cat, dmasks[i], dr[i], training, premasked=True, defer_act=defer)
         c.up_shape, c.x_shape, c.skip_hw = up_shape, tuple(cat.shape), (Hs, Ws)
         if checkpoint:
             c.x = None                                               # concat tensor: rebuilt in backward
         dec_ctx.append(c)
     O.tag("final.fwd")
-    logits = O.conv_fwd(d, P["final.weight"], P["final.bias"].detach(), 3, 1, 1)      # generator.py:29,56
+    if bnin_final:                                                                    # generator.py:29,56
+        logits = O.conv_fwd_bnin(dec_ctx[6].y, _bn_in(P, dec_ctx[6]), P["final.weight"], P["final.bias"].detach(), 3, 1, 1)
+    else:
+        logits = O.conv_fwd(d, P["final.weight"], P["final.bias"].detach(), 3, 1, 1)
     out = O.sigmoid_composite_fwd(logits.reshape(B, H, W), x, mask, out=out)            # generator.py:57-62
     if PROBE is not None:
         PROBE("fwd", "final", logits)
@@ -203,12 +211,24 @@ def generator_forward(P, x, mask, training=True, checkpoint=False, out=None):
             enc_ctx[i].x_shape = tuple(enc_ctx[i].x.shape)
             enc_ctx[i].x = None                                      # = ReLU(BN(y)) of the previous encoder layer
         d = None
-    return out, NS(enc=enc_ctx, dec=dec_ctx, d0=d, logits=logits, mask=mask, shape=(B, H, W), checkpoint=checkpoint)
+    return out, NS(enc=enc_ctx, dec=dec_ctx, d0=d, logits=logits, mask=mask, shape=(B, H, W), checkpoint=checkpoint,
+                   bnin_final=bnin_final)
 
 
 def _act_of(P, c):
     """Recompute a layer's ReLU(BN(y)) from its kept pre-BN output and batch statistics."""
     return O.bn_act_fwd(c.y, c.mean, c.rstd, P[f"{c.name}.bn.weight"], P[f"{c.name}.bn.bias"], O.ACT_RELU)
+
+
+def _bn_in(P, c):
+    """The BatchNorm + ReLU of layer context c as an `in_bn` tuple (applied on load by the consumer of c.y)."""
+    return (c.mean, c.rstd, P[f"{c.name}.bn.weight"], P[f"{c.name}.bn.bias"], O.ACT_RELU, 0.0)
+
+
+# dec1's ReLU(BN(.)) output has ONE consumer per pass, the 64 -> 1 `final` conv (forward: the conv; backward: its weight gradient),
+# an HBM-bound kernel that stages its source through LDS: the affine map + ReLU are applied there and the widest activation of the
+# network (B x H x W x 64) is neither written nor read back (TG_NO_BNIN=1: the two-pass form; same bits either way)
+BNIN_FINAL = os.environ.get("TG_NO_BNIN") is None
 
 
 def generator_backward(P, ctx, dout, want_dx=False, gbuf=None, on_ready=None):
@@ -222,13 +242,15 @@ def generator_backward(P, ctx, dout, want_dx=False, gbuf=None, on_ready=None):
     if PROBE is not None:
         PROBE("bwd", "gen", dout)
         PROBE("bwd", "final", dz)
-    d0 = _act_of(P, ctx.dec[6]) if ckpt else ctx.d0
+    bnin = getattr(ctx, "bnin_final", False)
+    # (BN-on-load: `final`'s input is dec1's PRE-BatchNorm output + its statistics -- nothing to recompute under checkpointing)
+    d0 = ctx.dec[6].y if bnin else (_act_of(P, ctx.dec[6]) if ckpt else ctx.d0)
     O.tag("final.dgrad")
     da = O.conv_dgrad(dz, P["final.weight"], tuple(d0.shape), 3, 1, 1)
     O.tag("final.wgrad")
     grads["final.weight"], grads["final.bias"] = _wgrad(gbuf, (d0, dz), lambda: O.conv_wgrad(
         d0, dz, P["final.weight"], 3, 1, 1, dw_out=gbuf["final.weight"] if gbuf is not None else None,
-        db_out=gbuf["final.bias"] if gbuf is not None else None))
+        db_out=gbuf["final.bias"] if gbuf is not None else None, in_bn=_bn_in(P, ctx.dec[6]) if bnin else None))
     _notify(on_ready, grads, ("final.bias", "final.weight"))
     del d0
     dskips = {}
@@ -443,10 +465,11 @@ def vgg_forward(V, img, keep=True, wino4=None):
     return h, NS(steps=steps)
 
 
-def vgg_backward(ctx, dfeat, nb=None, wino4=None):
+def vgg_backward(ctx, dfeat, nb=None, wino4=None, gated=False):
     """Input gradient only (weights are frozen, losses.py:33-34) for the first `nb` samples.
-    wino4 (dgrad kernels): None = F(4x4,3x3) where it pays (TG_VGG_WINO4=0: never); True / False force."""
-    da, gated = dfeat, False
+    wino4 (dgrad kernels): None = F(4x4,3x3) where it pays (TG_VGG_WINO4=0: never); True / False force.
+    gated: dfeat is already the gradient in front of the trunk's last ReLU (O.l1_mean(..., relu_gate=True))."""
+    da = dfeat
     steps = ctx.steps
     w4 = wino4
     for i in range(len(steps) - 1, -1, -1):

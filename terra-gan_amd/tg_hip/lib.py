@@ -28,6 +28,10 @@ class TgMaskPyramid(C.Structure):
     _fields_ = [("nops", C.c_int32), ("_pad", C.c_int32), ("op", TgMaskOp * TG_MASK_PYRAMID_MAX)]
 
 
+class TgBnAct(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("mean", "rstd", "gamma", "beta")] + [("act", C.c_int32), ("slope", C.c_float)]
+
+
 class TgError(RuntimeError):
     pass
 
@@ -53,6 +57,9 @@ SIGNATURES = {
     "tg_conv_wprep_run": (I, [P, I, P]),
     "tg_conv_fwd_p": (I, [CP, P, P, P, P, P, P, I, F, P, P, SZ, P]),
     "tg_conv_fwd_pool": (I, [CP, P, P, P, P, P, P, I, F, P, P, P, SZ, P]),
+    "tg_conv_bnin_supported": (I, [CP, I]),
+    "tg_conv_fwd_bnin": (I, [CP, P, C.POINTER(TgBnAct), P, P, I, F, P, P, SZ, P]),
+    "tg_conv_wgrad_bnin": (I, [CP, P, C.POINTER(TgBnAct), P, P, P, P, SZ, P]),
     "tg_conv_dgrad_p": (I, [CP, P, P, P, P, P, I, F, P, I, P, SZ, P]),
     "tg_conv_wgrad_ws_bytes": (SZ, [CP]),
     "tg_conv_wgrad": (I, [CP, P, P, P, P, P, P, SZ, P]),
@@ -77,6 +84,7 @@ SIGNATURES = {
     "tg_pixel_losses": (I, [P, P, P, P, I, I, I, F, F, F, F, P, P, P, I, P, SZ, P]),
     "tg_reduce_ws_bytes": (SZ, [I64]),
     "tg_l1_mean": (I, [P, P, I64, F, P, P, P, P, SZ, P]),
+    "tg_l1_mean_relu": (I, [P, P, I64, F, P, P, P, P, SZ, P]),
     "tg_bce_logits": (I, [P, I64, F, F, P, P, P, P, SZ, P]),
     "tg_adam": (I, [P, P, P, P, I64, D, D, D, D, I, F, P]),
     "tg_adam_multi": (I, [P, P, I, I, D, D, D, D, I, F, P]),

@@ -226,6 +226,39 @@ def conv_fwd(x, w, bias, k, stride, pad, in_mask=None, ratio=None, act=ACT_NONE,
     return y
 
 
+def _bn_act(in_bn):
+    """(mean, rstd, gamma, beta[, act[, slope]]) -> TgBnAct (the tensors stay referenced by the caller's tuple)."""
+    mean, rstd, gamma, beta = in_bn[:4]
+    for t in (mean, rstd, gamma, beta):
+        _chk(t, "in_bn")
+    act = in_bn[4] if len(in_bn) > 4 else ACT_RELU
+    slope = in_bn[5] if len(in_bn) > 5 else 0.0
+    return L.TgBnAct(mean.data_ptr(), rstd.data_ptr(), gamma.detach().data_ptr(), beta.detach().data_ptr(), act, slope)
+
+
+def conv_bnin_supported(x_shape, cout, k, stride, pad, wgrad=False):
+    """Can conv_fwd_bnin / conv_wgrad_bnin take this layer (input = act(BN(x)) applied while the kernel stages x)?"""
+    B, H, W, Cin = x_shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    g = L.TgConv(B, H, W, Cin, Ho, Wo, cout, k, stride, pad, _precision)
+    return bool(_lib().tg_conv_bnin_supported(C.byref(g), 1 if wgrad else 0))
+
+
+def conv_fwd_bnin(x, in_bn, w, bias, k, stride, pad, act=ACT_NONE, slope=0.0):
+    """conv(act_bn(BN(x)), w) + bias with the BatchNorm + activation of `in_bn` applied on load (tg_conv_fwd_bnin)."""
+    _chk(x, "x"); _chk(bias, "bias")
+    wv = weight_view(w)
+    _chk(wv, "weight")
+    g = conv_geom(x, wv.shape[0], k, stride, pad)
+    y = empty(g.B, g.Ho, g.Wo, g.Cout, like=x)
+    lib = _lib()
+    ws = workspace(lib.tg_conv_fwd_ws_bytes(C.byref(g)))
+    bn = _bn_act(in_bn)
+    L.check(lib.tg_conv_fwd_bnin(C.byref(g), _p(x), C.byref(bn), _p(wv), _p(bias), act, slope, _p(y), _p(ws), ws.numel() * 4, _stream()),
+            "tg_conv_fwd_bnin")
+    return y
+
+
 def conv_dgrad(dy, w, x_shape, k, stride, pad, in_mask=None, out=None, gate=None, gate_act=ACT_RELU, gate_slope=0.0, wino4=False):
     """dx for an input of shape x_shape=[B,H,W,Cin]; accumulates into `out` when given.  `gate` = output of the
     activation that produced x: its backward is fused into the epilogue (dx *= act'(gate))."""
@@ -245,9 +278,10 @@ def conv_dgrad(dy, w, x_shape, k, stride, pad, in_mask=None, out=None, gate=None
     return dx
 
 
-def conv_wgrad(x, dy, w, k, stride, pad, in_mask=None, want_bias=True, dw_out=None, db_out=None):
+def conv_wgrad(x, dy, w, k, stride, pad, in_mask=None, want_bias=True, dw_out=None, db_out=None, in_bn=None):
     """Returns (dw, db): dw has the parameter's logical shape AND strides (channels_last).  dw_out / db_out:
-    preallocated destinations (persistent gradient buffers) with the parameter's layout."""
+    preallocated destinations (persistent gradient buffers) with the parameter's layout.
+    in_bn: the layer's input is act(BN(x)), applied on load (tg_conv_wgrad_bnin; see conv_bnin_supported)."""
     _chk(x, "x"); _chk(dy, "dy"); _chk(in_mask, "in_mask")
     wv = weight_view(w)
     B, H, W, Cin = x.shape
@@ -260,6 +294,12 @@ def conv_wgrad(x, dy, w, k, stride, pad, in_mask=None, want_bias=True, dw_out=No
     db = (db_out if db_out is not None else empty(g.Cout, like=x)) if want_bias else None
     lib = _lib()
     ws = workspace(lib.tg_conv_wgrad_ws_bytes(C.byref(g)))
+    if in_bn is not None:
+        assert in_mask is None
+        bn = _bn_act(in_bn)
+        L.check(lib.tg_conv_wgrad_bnin(C.byref(g), _p(x), C.byref(bn), _p(dy), _p(dwv), _p(db), _p(ws), ws.numel() * 4, _stream()),
+                "tg_conv_wgrad_bnin")
+        return dwv.permute(0, 3, 1, 2), db
     L.check(lib.tg_conv_wgrad(C.byref(g), _p(x), _p(in_mask), _p(dy), _p(dwv), _p(db), _p(ws), ws.numel() * 4, _stream()),
             "tg_conv_wgrad")
     return dwv.permute(0, 3, 1, 2), db
@@ -396,13 +436,15 @@ def bn_stats(y, running_mean=None, running_var=None, nbt=None, eps=BN_EPS, momen
 
 
 def bn_fwd(y, gamma, beta, act, slope=0.0, running_mean=None, running_var=None, nbt=None, out=None, eps=BN_EPS,
-           momentum=BN_MOMENTUM):
-    """Training-mode BatchNorm forward: (mean, rstd, out) = bn_stats + bn_act_fwd in one call (one launch on small maps)."""
+           momentum=BN_MOMENTUM, apply=True):
+    """Training-mode BatchNorm forward: (mean, rstd, out) = bn_stats + bn_act_fwd in one call (one launch on small maps).
+    apply=False: statistics (and running-statistics update) only, out = None -- the consumer applies the affine map + activation
+    while it loads y (conv_fwd_bnin / conv_wgrad_bnin)."""
     _chk(y, "y"); _chk(out, "out")
     Cc = y.shape[-1]
     rows = y.numel() // Cc
     mean, rstd = empty(Cc, like=y), empty(Cc, like=y)
-    if out is None:
+    if out is None and apply:
         out = torch.empty_like(y)
     lib = _lib()
     ws = workspace(lib.tg_bn_ws_bytes(rows, Cc))
@@ -574,14 +616,15 @@ def pixel_losses(pred, target, mask, w_l1, w_tv, w_bnd, l1_weight=None, gscale=N
     return out5, (dpred if want_grad else None)
 
 
-def l1_mean(a, b, coef=1.0, gscale=None, want_grad=True):
+def l1_mean(a, b, coef=1.0, gscale=None, want_grad=True, relu_gate=False):
+    """relu_gate: `a` is a ReLU output; the gradient returned is the one in front of that ReLU (zero where a <= 0)."""
     _chk(a, "a"); _chk(b, "b")
     out = empty(1, like=a)
     da = torch.empty_like(a) if want_grad else None
     lib = _lib()
     ws = workspace(lib.tg_reduce_ws_bytes(a.numel()))
-    L.check(lib.tg_l1_mean(_p(a), _p(b), a.numel(), coef, _p(gscale), _p(out), _p(da), _p(ws), ws.numel() * 4, _stream()),
-            "tg_l1_mean")
+    fn = lib.tg_l1_mean_relu if relu_gate else lib.tg_l1_mean
+    L.check(fn(_p(a), _p(b), a.numel(), coef, _p(gscale), _p(out), _p(da), _p(ws), ws.numel() * 4, _stream()), "tg_l1_mean")
     return out, da
 
 

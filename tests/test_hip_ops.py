@@ -353,3 +353,71 @@ def test_small_batchnorm_one_launch_forms(dev, rows, C, act, with_ratio):
     close(db_, dbeta, 2e-5, 2e-5)
     close(dyd.reshape(rows, C), dy, 5e-5, 1e-5)
     close(dbias, dy.sum(0), 1e-4, 1e-4 * float(dy.abs().sum(0).max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64), (3, 40, 24), (1, 20, 52), (2, 4, 16)])
+def test_conv_bn_on_load_equals_the_two_call_form(dev, shape):
+    """tg_conv_fwd_bnin / tg_conv_wgrad_bnin (`final` over dec1's ReLU(BN(y)), the activation never written) against
+    tg_bn_act_fwd + tg_conv_fwd / tg_conv_wgrad: the staging applies the same rounding sequence, so the results are the same bits;
+    geometries without the kernel say so through tg_conv_bnin_supported."""
+    from tg_hip import ops as O
+    B, H, W = shape
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    y = (torch.randn(B, H, W, 64, generator=g) * 2 + 0.5).to(dev)
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.3).to(dev)
+    mean, rstd = O.bn_stats(y)
+    w = (torch.randn(1, 64, 3, 3, generator=g) * 0.1).contiguous(memory_format=torch.channels_last).to(dev)
+    b = torch.randn(1, generator=g).to(dev)
+    dz = torch.randn(B, H, W, 1, generator=g).to(dev)
+    assert O.conv_bnin_supported(tuple(y.shape), 1, 3, 1, 1) and O.conv_bnin_supported(tuple(y.shape), 1, 3, 1, 1, wgrad=True)
+    a = O.bn_act_fwd(y, mean, rstd, gamma, beta, O.ACT_RELU)
+    bn = (mean, rstd, gamma, beta, O.ACT_RELU, 0.0)
+    z0 = O.conv_fwd(a, w, b, 3, 1, 1)
+    z1 = O.conv_fwd_bnin(y, bn, w, b, 3, 1, 1)
+    assert torch.equal(z0, z1), float((z0 - z1).abs().max())
+    dw0, db0 = O.conv_wgrad(a, dz, w, 3, 1, 1)
+    dw1, db1 = O.conv_wgrad(y, dz, w, 3, 1, 1, in_bn=bn)
+    assert torch.equal(dw0, dw1) and torch.equal(db0, db1), float((dw0 - dw1).abs().max())
+    # and against fp64
+    ad = torch.relu((y.double().cpu() - mean.double().cpu()) * rstd.double().cpu() * gamma.double().cpu() + beta.double().cpu())
+    zr = F.conv2d(nchw(ad), w.double().cpu(), b.double().cpu(), 1, 1)
+    close(nchw(z1), zr, rtol=1e-4, atol=1e-4)
+    for bad in [(B, H, W, 128), (B, H, W + 2, 64) if W % 4 == 0 else (B, 2, W, 64)]:
+        if bad[2] % 4 or bad[3] != 64 or bad[1] < 4:
+            assert not O.conv_bnin_supported(bad, 1, 3, 1, 1)
+    assert not O.conv_bnin_supported(tuple(y.shape), 64, 3, 1, 1)
+
+
+def test_generator_with_and_without_bn_on_load(dev):
+    """The generator step with dec1's BatchNorm applied on load by `final` (default) and with the activation written and read back
+    (TG_NO_BNIN=1 / engine.BNIN_FINAL = False): outputs, every gradient and the running statistics bit for bit equal."""
+    from mvp_gan.src.models.generator import PConvUNet
+    from tg_hip import engine as E
+    torch.manual_seed(3)
+    res = []
+    G0 = PConvUNet()
+    sd = {k: v.clone() for k, v in G0.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 64, 64, generator=g).to(dev)
+    m = (torch.rand(2, 64, 64, generator=g) > 0.3).float().to(dev)
+    dout = torch.randn(2, 64, 64, generator=g).to(dev)
+    old = E.BNIN_FINAL
+    try:
+        for flag in (True, False):
+            E.BNIN_FINAL = flag
+            G = PConvUNet()
+            G.load_state_dict(sd)
+            G = G.to(dev)
+            P = G._tensors()
+            out, ctx = E.generator_forward(P, x * m, m, training=True)
+            assert ctx.bnin_final == flag
+            grads, _ = E.generator_backward(P, ctx, dout.clone())
+            res.append((out.clone(), {k: v.clone() for k, v in grads.items()}, {k: v.clone() for k, v in G.named_buffers()}))
+    finally:
+        E.BNIN_FINAL = old
+    (o1, g1, b1), (o0, g0, b0) = res
+    assert torch.equal(o1, o0)
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k
+    for k in b0:
+        assert torch.equal(b1[k], b0[k]), k

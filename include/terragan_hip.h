@@ -219,6 +219,13 @@ int tg_act_bwd(const float* dout, const float* out, int64_t rows, int C, int act
  * `input * mask` of the consuming PConv2d (pconv.py:27), so that conv and its wgrad read it unmasked. */
 int tg_upcat_fwd(const float* up, const float* skip, const float* out_mask, int B, int h, int w,
                  int Cu, int H, int W, int Cs, float* out, tg_stream_t stream);
+/* The same with `up` = the PRE-BatchNorm output of the decoder layer below: the interpolation runs over act(BN(up)) formed on
+ * load (TgBnAct: see tg_conv_fwd_bnin above), so that layer's activation -- read by nothing else
+ * (generator.py:66-76 consumes it once, through F.interpolate) -- is never written.  Exact x2 geometries only
+ * (H == 2h, W == 2w, Cu % 4 == 0, Cs % 4 == 0): tg_upcat_bn_supported; same bits as tg_bn_act_fwd + tg_upcat_fwd. */
+int tg_upcat_bn_supported(int B, int h, int w, int Cu, int H, int W, int Cs);
+int tg_upcat_fwd_bn(const float* up, const TgBnAct* bn, const float* skip, const float* out_mask, int B, int h, int w,
+                    int Cu, int H, int W, int Cs, float* out, tg_stream_t stream);
 /* adjoint: dup[B][h][w][Cu] = bilinear_up2^T(dout[..., :Cu]);  dskip = dout[..., Cu:]. */
 int tg_upcat_bwd(const float* dout, int B, int h, int w, int Cu, int H, int W, int Cs, float* dup,
                  float* dskip, tg_stream_t stream);

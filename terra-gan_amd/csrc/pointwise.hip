@@ -945,9 +945,18 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict_
 // loads for 4 outputs instead of 4 per output, two interpolation set-ups per axis instead of one per output element); the
 // skip half of the concat is a second index range of the same launch.  Same interpolation expression, same operand order as
 // upcat_fwd_kernel: bit-identical results (tests/test_hip_ops.py::test_upcat_x2_equals_generic).
+// BNIN (tg_upcat_fwd_bn): `up` is the PRE-BatchNorm output of the decoder layer below and the interpolation runs over
+// act(BN(up)), formed as the nine source quads arrive (bn_affine: the rounding sequence of bn_act_fwd, so the concat tensor equals
+// the two-pass form bit for bit) -- that layer's activation is never written.
+struct UpBn {
+    const float *mean, *rstd, *gamma, *beta;
+    int act;
+    float slope;
+};
+template <bool BNIN>
 __global__ __launch_bounds__(256) void upcat_fwd_x2_kernel(const float* __restrict__ up, const float* __restrict__ skip,
                                                            const float* __restrict__ omask, int B, int h, int w, int Cu, int Cs,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, const UpBn bn) {
     const int Ct = Cu + Cs, H = 2 * h, W = 2 * w;
     const int cu4 = Cu >> 2, cs4 = Cs >> 2;
     const uint32_t nA = (uint32_t)B * h * w * cu4, nB = (uint32_t)B * H * W * cs4;
@@ -966,6 +975,16 @@ __global__ __launch_bounds__(256) void upcat_fwd_x2_kernel(const float* __restri
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
                     T[i][j] = *reinterpret_cast<const f32x4*>(up + (((size_t)b * h + ry[i]) * w + rx[j]) * Cu + c);
+            if constexpr (BNIN) {
+                const f32x4 mv = *reinterpret_cast<const f32x4*>(bn.mean + c), rv = *reinterpret_cast<const f32x4*>(bn.rstd + c);
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(bn.gamma + c), bv = *reinterpret_cast<const f32x4*>(bn.beta + c);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) T[i][j][e] = apply_act(bn_affine(T[i][j][e], mv[e], rv[e], gv[e], bv[e]), bn.act, bn.slope);
+            }
             Lerp ly[2], lx[2];
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
@@ -1002,6 +1021,24 @@ __global__ __launch_bounds__(256) void upcat_fwd_x2_kernel(const float* __restri
         }
     }
 }
+static bool upcat_x2_ok(int B, int h, int w, int Cu, int H, int W, int Cs) {
+    const bool no_x2 = getenv("TG_NO_UPCAT_X2") != nullptr;      // read per call: tests flip it at run time
+    return !no_x2 && (int64_t)B * H * W * (Cu + Cs) < ((int64_t)1 << 31) && H == 2 * h && W == 2 * w && Cu % 4 == 0 && Cs % 4 == 0;
+}
+extern "C" int tg_upcat_bn_supported(int B, int h, int w, int Cu, int H, int W, int Cs) {
+    return B > 0 && h > 0 && w > 0 && Cu > 0 && Cs >= 0 && upcat_x2_ok(B, h, w, Cu, H, W, Cs) ? 1 : 0;
+}
+extern "C" int tg_upcat_fwd_bn(const float* up, const TgBnAct* bn, const float* skip, const float* out_mask, int B, int h, int w, int Cu,
+                               int H, int W, int Cs, float* out, tg_stream_t stream) {
+    TG_REQUIRE(up && out && bn && bn->mean && bn->rstd && bn->gamma && bn->beta, "tg_upcat_fwd_bn: null pointer");
+    TG_REQUIRE(Cs == 0 || skip, "tg_upcat_fwd_bn: skip is NULL but Cs > 0");
+    TG_REQUIRE(tg_upcat_bn_supported(B, h, w, Cu, H, W, Cs), "tg_upcat_fwd_bn: geometry not supported (ask tg_upcat_bn_supported first)");
+    const int64_t items = (int64_t)B * h * w * (Cu / 4) + (int64_t)B * H * W * (Cs / 4);
+    const UpBn ub{bn->mean, bn->rstd, bn->gamma, bn->beta, bn->act, bn->slope};
+    hipLaunchKernelGGL(upcat_fwd_x2_kernel<true>, dim3(ew_grid(items, 256)), dim3(256), 0, S(stream), up, skip, out_mask, B, h, w, Cu, Cs, out, ub);
+    TG_CHECK_LAUNCH("upcat_fwd_x2_kernel");
+    return TG_OK;
+}
 extern "C" int tg_upcat_fwd(const float* up, const float* skip, const float* out_mask, int B, int h, int w, int Cu, int H, int W,
                             int Cs, float* out, tg_stream_t stream) {
     TG_REQUIRE(up && out && B > 0 && h > 0 && w > 0 && Cu > 0 && H > 0 && W > 0 && Cs >= 0, "tg_upcat_fwd: bad arguments");
@@ -1009,10 +1046,10 @@ extern "C" int tg_upcat_fwd(const float* up, const float* skip, const float* out
     const int offy = floordiv2(H - 2 * h), offx = floordiv2(W - 2 * w);
     const int Ct = Cu + Cs;
     const bool small = (int64_t)B * H * W * Ct < ((int64_t)1 << 31);
-    const bool no_x2 = getenv("TG_NO_UPCAT_X2") != nullptr;      // read per call: tests flip it at run time
-    if (!no_x2 && small && H == 2 * h && W == 2 * w && Cu % 4 == 0 && Cs % 4 == 0) {
+    if (upcat_x2_ok(B, h, w, Cu, H, W, Cs)) {
         const int64_t items = (int64_t)B * h * w * (Cu / 4) + (int64_t)B * H * W * (Cs / 4);
-        hipLaunchKernelGGL(upcat_fwd_x2_kernel, dim3(ew_grid(items, 256)), dim3(256), 0, S(stream), up, skip, out_mask, B, h, w, Cu, Cs, out);
+        hipLaunchKernelGGL(upcat_fwd_x2_kernel<false>, dim3(ew_grid(items, 256)), dim3(256), 0, S(stream), up, skip, out_mask, B, h, w, Cu, Cs, out,
+                           UpBn{});
         TG_CHECK_LAUNCH("upcat_fwd_x2_kernel");
         return TG_OK;
     }

@@ -186,13 +186,27 @@ def generator_forward(P, x, mask, training=True, checkpoint=False, out=None):
     d, dec_ctx = e[7], []
     fshape = (B, H, W, G_DEC[6][2])
     bnin_final = BNIN_FINAL and O.conv_bnin_supported(fshape, 1, 3, 1, 1) and O.conv_bnin_supported(fshape, 1, 3, 1, 1, wgrad=True)
+    up_c = None                                                      # context of the layer whose ReLU(BN(y)) was deferred to this upcat
     for i, (name, _ci, _co, k, s, p) in enumerate(G_DEC):
         skip = e[6 - i] if i < 6 else None
         Hs, Ws = (skip.shape[1], skip.shape[2]) if skip is not None else (H, W)
-        up_shape = tuple(d.shape)
-        cat = O.upcat_fwd(d, skip, Hs, Ws, out_mask=dmasks[i])       # = merged_feature * merged_mask
-        defer = i == 6 and bnin_final
+        if up_c is not None:
+            up_shape = tuple(up_c.y.shape)
+            cat = O.upcat_fwd(up_c.y, skip, Hs, Ws, out_mask=dmasks[i], up_bn=_bn_in(P, up_c))
+        else:
+            up_shape = tuple(d.shape)
+            cat = O.upcat_fwd(d, skip, Hs, Ws, out_mask=dmasks[i])   # = merged_feature * merged_mask
+        if i == 6:
+            defer = bnin_final
+        else:
+            # this layer's activation has one reader, the next level's upsample: deferred to it where that kernel can (exact x2
+            # levels) and the BatchNorm is a two-launch one anyway (the small maps' one-launch form already applies it)
+            nskip = e[5 - i] if i < 5 else None
+            nH, nW = (nskip.shape[1], nskip.shape[2]) if nskip is not None else (H, W)
+            defer = BNIN_UPCAT and Hs * Ws * B > O.BN_SMALL_ROWS and \
+                O.upcat_bn_supported((B, Hs, Ws, _co), None if nskip is None else tuple(nskip.shape), nH, nW)
         d, c = _pconv_fwd(P, name, k, s, p, cat, dmasks[i], dr[i], training, premasked=True, defer_act=defer)
+        up_c = c if (defer and i < 6) else None
         c.up_shape, c.x_shape, c.skip_hw = up_shape, tuple(cat.shape), (Hs, Ws)
         if checkpoint:
             c.x = None                                               # concat tensor: rebuilt in backward
@@ -229,6 +243,8 @@ def _bn_in(P, c):
 # an HBM-bound kernel that stages its source through LDS: the affine map + ReLU are applied there and the widest activation of the
 # network (B x H x W x 64) is neither written nor read back (TG_NO_BNIN=1: the two-pass form; same bits either way)
 BNIN_FINAL = os.environ.get("TG_NO_BNIN") is None
+# dec2 ... dec5 the same way into the next level's upsample + concat (TG_NO_BNIN_UPCAT=1 / TG_NO_BNIN=1: off)
+BNIN_UPCAT = os.environ.get("TG_NO_BNIN") is None and os.environ.get("TG_NO_BNIN_UPCAT") is None
 
 
 def generator_backward(P, ctx, dout, want_dx=False, gbuf=None, on_ready=None):
@@ -257,10 +273,15 @@ def generator_backward(P, ctx, dout, want_dx=False, gbuf=None, on_ready=None):
     for i in range(6, -1, -1):                     # dec1 ... dec7
         c = ctx.dec[i]
         if ckpt:                                   # rebuild this layer's (pre-masked) concat input
-            up_src = _act_of(P, ctx.dec[i - 1]) if i > 0 else _act_of(P, ctx.enc[6])
+            below = ctx.dec[i - 1] if i > 0 else ctx.enc[6]
             skip = _act_of(P, ctx.enc[5 - i]) if i < 6 else None
-            c.x = O.upcat_fwd(up_src, skip, c.skip_hw[0], c.skip_hw[1], out_mask=c.in_mask)
-            del up_src, skip
+            if BNIN_UPCAT and O.upcat_bn_supported(tuple(below.y.shape), None if skip is None else tuple(skip.shape), *c.skip_hw):
+                c.x = O.upcat_fwd(below.y, skip, c.skip_hw[0], c.skip_hw[1], out_mask=c.in_mask, up_bn=_bn_in(P, below))
+            else:
+                up_src = _act_of(P, below)
+                c.x = O.upcat_fwd(up_src, skip, c.skip_hw[0], c.skip_hw[1], out_mask=c.in_mask)
+                del up_src
+            del skip
         dcat = _pconv_bwd(P, c, da, grads, gbuf=gbuf, on_ready=on_ready)
         if ckpt:
             c.x = None

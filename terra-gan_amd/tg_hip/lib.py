@@ -75,6 +75,8 @@ SIGNATURES = {
     "tg_bn_act_bwd": (I, [P, P, I64, I, P, P, P, P, I, F, P, P, P, P, P, P, SZ, P]),
     "tg_act_bwd": (I, [P, P, I64, I, I, F, P, P, P]),
     "tg_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P]),
+    "tg_upcat_bn_supported": (I, [I, I, I, I, I, I, I]),
+    "tg_upcat_fwd_bn": (I, [P, C.POINTER(TgBnAct), P, P, I, I, I, I, I, I, I, P, P]),
     "tg_upcat_bwd": (I, [P, I, I, I, I, I, I, I, P, P, P]),
     "tg_sigmoid_composite_fwd": (I, [P, P, P, I64, P, P]),
     "tg_sigmoid_composite_bwd": (I, [P, P, P, I64, P, P, P]),

@@ -422,6 +422,9 @@ def mask_pyramid(mask, enc, dec):
     return m, er, dmasks, dr
 
 
+BN_SMALL_ROWS = 2048          # tg_bn_fwd / tg_bn_act_bwd take their one-launch form up to this many rows (pointwise.hip)
+
+
 def bn_stats(y, running_mean=None, running_var=None, nbt=None, eps=BN_EPS, momentum=BN_MOMENTUM):
     _chk(y, "y")
     Cc = y.shape[-1]
@@ -548,11 +551,24 @@ def act_bwd(dout, out, act, slope=0.0, ratio=None, inplace=True):
     return din
 
 
-def upcat_fwd(up, skip, H, W, out_mask=None):
+def upcat_bn_supported(up_shape, skip_shape, H, W):
+    """Can upcat_fwd(..., up_bn=...) apply the BatchNorm + activation of the layer below while it loads `up`?"""
+    B, h, w, Cu = up_shape
+    Cs = 0 if skip_shape is None else skip_shape[3]
+    return bool(_lib().tg_upcat_bn_supported(B, h, w, Cu, H, W, Cs))
+
+
+def upcat_fwd(up, skip, H, W, out_mask=None, up_bn=None):
+    """up_bn = (mean, rstd, gamma, beta[, act[, slope]]): `up` is a PRE-BatchNorm conv output, act(BN(up)) is formed on load."""
     _chk(up, "up"); _chk(skip, "skip"); _chk(out_mask, "out_mask")
     B, h, w, Cu = up.shape
     Cs = 0 if skip is None else skip.shape[3]
     out = empty(B, H, W, Cu + Cs, like=up)
+    if up_bn is not None:
+        bn = _bn_act(up_bn)
+        L.check(_lib().tg_upcat_fwd_bn(_p(up), C.byref(bn), _p(skip), _p(out_mask), B, h, w, Cu, H, W, Cs, _p(out), _stream()),
+                "tg_upcat_fwd_bn")
+        return out
     L.check(_lib().tg_upcat_fwd(_p(up), _p(skip), _p(out_mask), B, h, w, Cu, H, W, Cs, _p(out), _stream()), "tg_upcat_fwd")
     return out
 

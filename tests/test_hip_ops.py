@@ -389,8 +389,9 @@ def test_conv_bn_on_load_equals_the_two_call_form(dev, shape):
 
 
 def test_generator_with_and_without_bn_on_load(dev):
-    """The generator step with dec1's BatchNorm applied on load by `final` (default) and with the activation written and read back
-    (TG_NO_BNIN=1 / engine.BNIN_FINAL = False): outputs, every gradient and the running statistics bit for bit equal."""
+    """The generator step with the decoder's BatchNorm + ReLU applied on load by the consumers (`final` for dec1, the next level's
+    upsample + concat for dec2 ... dec5: the default) and with the activations written and read back (TG_NO_BNIN=1 /
+    engine.BNIN_FINAL = BNIN_UPCAT = False): outputs, every gradient and the running statistics bit for bit equal."""
     from mvp_gan.src.models.generator import PConvUNet
     from tg_hip import engine as E
     torch.manual_seed(3)
@@ -398,13 +399,13 @@ def test_generator_with_and_without_bn_on_load(dev):
     G0 = PConvUNet()
     sd = {k: v.clone() for k, v in G0.state_dict().items()}
     g = torch.Generator().manual_seed(5)
-    x = torch.rand(2, 64, 64, generator=g).to(dev)
-    m = (torch.rand(2, 64, 64, generator=g) > 0.3).float().to(dev)
-    dout = torch.randn(2, 64, 64, generator=g).to(dev)
-    old = E.BNIN_FINAL
+    x = torch.rand(3, 128, 128, generator=g).to(dev)
+    m = (torch.rand(3, 128, 128, generator=g) > 0.3).float().to(dev)
+    dout = torch.randn(3, 128, 128, generator=g).to(dev)
+    old = E.BNIN_FINAL, E.BNIN_UPCAT
     try:
         for flag in (True, False):
-            E.BNIN_FINAL = flag
+            E.BNIN_FINAL = E.BNIN_UPCAT = flag          # (dec2 and dec3 have more than 2048 rows here: deferred to their upsample)
             G = PConvUNet()
             G.load_state_dict(sd)
             G = G.to(dev)
@@ -414,10 +415,29 @@ def test_generator_with_and_without_bn_on_load(dev):
             grads, _ = E.generator_backward(P, ctx, dout.clone())
             res.append((out.clone(), {k: v.clone() for k, v in grads.items()}, {k: v.clone() for k, v in G.named_buffers()}))
     finally:
-        E.BNIN_FINAL = old
+        E.BNIN_FINAL, E.BNIN_UPCAT = old
     (o1, g1, b1), (o0, g0, b0) = res
     assert torch.equal(o1, o0)
     for k in g0:
         assert torch.equal(g1[k], g0[k]), k
     for k in b0:
         assert torch.equal(b1[k], b0[k]), k
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 32), (1, 9, 13, 128, 0), (3, 8, 20, 32, 64)])
+def test_upcat_bn_on_load_equals_the_two_call_form(dev, shape):
+    """tg_upcat_fwd_bn (upsample + concat over ReLU(BN(up)) formed on load) against tg_bn_act_fwd + tg_upcat_fwd: same bits."""
+    from tg_hip import ops as O
+    B, h, w, Cu, Cs = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    y = (torch.randn(B, h, w, Cu, generator=g) * 1.5 - 0.2).to(dev)
+    gamma, beta = (torch.rand(Cu, generator=g) + 0.5).to(dev), (torch.randn(Cu, generator=g) * 0.3).to(dev)
+    mean, rstd = O.bn_stats(y)
+    skip = torch.randn(B, 2 * h, 2 * w, Cs, generator=g).to(dev) if Cs else None
+    om = (torch.rand(B, 2 * h, 2 * w, generator=g) > 0.3).float().to(dev)
+    assert O.upcat_bn_supported(tuple(y.shape), None if skip is None else tuple(skip.shape), 2 * h, 2 * w)
+    assert not O.upcat_bn_supported(tuple(y.shape), None if skip is None else tuple(skip.shape), 2 * h + 1, 2 * w)
+    a = O.bn_act_fwd(y, mean, rstd, gamma, beta, O.ACT_RELU)
+    c0 = O.upcat_fwd(a, skip, 2 * h, 2 * w, out_mask=om)
+    c1 = O.upcat_fwd(y, skip, 2 * h, 2 * w, out_mask=om, up_bn=(mean, rstd, gamma, beta, O.ACT_RELU, 0.0))
+    assert torch.equal(c0, c1), float((c0 - c1).abs().max())

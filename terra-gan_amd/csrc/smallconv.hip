@@ -27,16 +27,32 @@ struct C1Geom {
 // stage the [PH][PW] source patch of tile (b, oy0, ox0): zero outside the image, mask pre-multiplied
 __device__ __forceinline__ void c1_stage_patch(const float* __restrict__ src, const float* __restrict__ amask, float* patch,
                                                int b, int py0, int px0, int PH, int PW, int IH, int IW) {
-    for (int i = threadIdx.x; i < PH * PW; i += 256) {
-        const int py = i / PW, px = i - py * PW;
-        const int iy = py0 + py, ix = px0 + px;
-        float v = 0.f;
-        if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) {
-            const size_t pix = ((size_t)b * IH + iy) * IW + ix;
-            v = src[pix];
-            if (amask) v *= amask[pix];
+    // Six elements per thread and trip (a 37 x 37 patch -- 7x7 stride 2 -- is one trip), loads unconditional at clamped
+    // addresses and all in flight together: the rolled, branchy form (load, wait, store per element) serialised up to six memory
+    // round trips per tile, ~10 us of the 18 us a tile of the persistent weight-gradient kernel took.
+    constexpr int U = 6;
+    const int n = PH * PW;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * U) {
+        float v[U], m[U];
+        bool ok[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int i = i0 + 256 * k;
+            const int ic = i < n ? i : 0;
+            const int py = ic / PW, px = ic - py * PW;
+            const int iy = py0 + py, ix = px0 + px;
+            ok[k] = i < n && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+            const size_t pix = ok[k] ? ((size_t)b * IH + iy) * IW + ix : 0;
+            v[k] = src[pix];
+            m[k] = amask ? amask[pix] : 1.f;
         }
-        patch[i] = v;
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int i = i0 + 256 * k;
+            float o = v[k];
+            if (amask) o *= m[k];
+            if (i < n) patch[i] = ok[k] ? o : 0.f;
+        }
     }
 }
 
@@ -659,13 +675,12 @@ __global__ __launch_bounds__(256) void c1wgrad_mfma_kernel(const WgradParams p, 
         tile /= q.tiles_x;
         const int tyi = tile % q.tiles_y, b = tile / q.tiles_y;
         const int oy0 = tyi * C1_T, ox0 = txi * C1_T;
-        __syncthreads();
-        c1_stage_patch(p.x, p.amask, patch, b, oy0 * p.stride - p.pad, ox0 * p.stride - p.pad, q.PH, q.PW, p.H, p.W);
-        __syncthreads();
-        // this wave's 64 pixels: rows 4*wave .. 4*wave+3, 16 columns; K step s = pixels 2s, 2s+1 (lane half h)
-#pragma unroll
-        for (int s8 = 0; s8 < 4; ++s8) {
-            float a[8][2], bv[8][NTT];
+        // this wave's 64 pixels: rows 4*wave .. 4*wave+3, 16 columns; K step s = pixels 2s, 2s+1 (lane half h), eight steps a batch.
+        // The dy words of a batch are requested one batch ahead (the first one ahead of the patch staging): with the loads issued
+        // and awaited inside the batch no memory request was in flight during its 32 MFMAs -- two waves per SIMD, nothing to hide
+        // the round trip behind (enc1 37 us, D conv0 51 us for 13.6 us of matrix time)
+        float an[8][2];
+        auto load_a = [&](int s8) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int s = 8 * s8 + u;
@@ -673,8 +688,30 @@ __global__ __launch_bounds__(256) void c1wgrad_mfma_kernel(const WgradParams p, 
                 const int oy = oy0 + ty_o, ox = ox0 + tx_o;
                 const bool in = oy < p.Ho && ox < p.Wo;
                 const float* dp = p.dy + (((size_t)b * p.Ho + (in ? oy : 0)) * p.Wo + (in ? ox : 0)) * p.Cout + co0 + li;
-                a[u][0] = in ? dp[0] : 0.f;
-                a[u][1] = in ? dp[32] : 0.f;
+                // unconditional loads (the address is clamped into the image): a branch around each pair makes the outstanding-load
+                // count unknowable to the compiler and every wait a vmcnt(0) -- which would also wait for the batch just requested
+                const float v0 = dp[0], v1 = dp[32];
+                an[u][0] = in ? v0 : 0.f;
+                an[u][1] = in ? v1 : 0.f;
+            }
+        };
+        load_a(0);
+        __syncthreads();
+        c1_stage_patch(p.x, p.amask, patch, b, oy0 * p.stride - p.pad, ox0 * p.stride - p.pad, q.PH, q.PW, p.H, p.W);
+        __syncthreads();
+#pragma unroll
+        for (int s8 = 0; s8 < 4; ++s8) {
+            float a[8][2], bv[8][NTT];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u][0] = an[u][0];
+                a[u][1] = an[u][1];
+            }
+            if (s8 < 3) load_a(s8 + 1);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = 8 * s8 + u;
+                const int ty_o = wave * 4 + (s >> 3), tx_o = ((2 * s) & 15) + h;
                 const int pbase = ty_o * p.stride * q.PW + tx_o * p.stride;
 #pragma unroll
                 for (int t = 0; t < NTT; ++t) bv[u][t] = tapok[t] ? patch[pbase + tapoff[t]] : 0.f;

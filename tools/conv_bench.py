@@ -31,6 +31,7 @@ SHAPES = [
     ("d3", 16, 32, 32, 256, 512, 4, 2, 1, False),
     ("final", 16, 256, 256, 64, 1, 3, 1, 1, False),
     ("enc1", 16, 256, 256, 1, 64, 7, 2, 3, True),
+    ("d0", 32, 256, 256, 1, 64, 4, 2, 1, False),
 ]
 
 

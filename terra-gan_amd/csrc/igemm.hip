@@ -323,6 +323,12 @@ __device__ __forceinline__ void igemm_body(const IGemmParams& p, const int bz) {
     const int t_end = min(p.T, t_begin + p.steps_per_split);
 
     f32x4 ra[A_LOADS], rw[B_LOADS];
+    // vector path: the source-mask value of a gathered quad is only FETCHED with it (rmk) and multiplied in when the step is
+    // stored to LDS.  With `if (ok) { v = load; v *= mask[pix]; }` every gather waited for its own two requests inside its
+    // branch before the next one could issue: a masked K step's loads went out one round trip after the other (enc4 forward
+    // 120 -> 117 us, its weight gradient 143 -> 131 us).  Out-of-range taps still issue no load at all: making the loads
+    // unconditional at clamped addresses helps the masked layers as much and costs the small-image dgrads 5-10 %.
+    float rmk[A_LOADS];
 
     // loader state for the NEXT K step (vector path): tap (l_ty, l_tx) and channel chunk l_ch, advanced
     // incrementally -- no integer division in the loop
@@ -353,14 +359,16 @@ __device__ __forceinline__ void igemm_body(const IGemmParams& p, const int bz) {
         for (int i = 0; i < A_LOADS; ++i) {
             if ((i & 3) != part) continue;
             int iy = ry[i] + g_dyy, ix = rx[i] + g_dxx;
-            bool ok = rv[i] && g_cv && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            const bool ok = rv[i] && g_cv && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            float mk = 1.f;
             if (ok) {
                 size_t pix = ((size_t)rb[i] * p.IH + iy) * p.IW + ix;
                 v = *reinterpret_cast<const f32x4*>(p.src + pix * p.C + g_c0);
-                if (p.amask) v *= p.amask[pix];
+                if (p.amask) mk = p.amask[pix];
             }
             ra[i] = v;
+            rmk[i] = mk;
         }
 #pragma unroll
         for (int j = 0; j < B_LOADS; ++j) {
@@ -369,6 +377,15 @@ __device__ __forceinline__ void igemm_body(const IGemmParams& p, const int bz) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (n < p.N && g_cv) v = *reinterpret_cast<const f32x4*>(p.wmat + (size_t)n * p.Kfull + g_widx);
             rw[j] = v;
+        }
+    };
+    // (vector path) the source mask of the step about to be stored
+    auto gfinish = [&]() {
+        if constexpr (!SCALAR) {
+            if (p.amask) {
+#pragma unroll
+                for (int i = 0; i < A_LOADS; ++i) ra[i] *= rmk[i];
+            }
         }
     };
     auto gload_scalar = [&](int t) {
@@ -423,6 +440,7 @@ __device__ __forceinline__ void igemm_body(const IGemmParams& p, const int bz) {
         }
     };
     auto sstore = [&](int buf) {
+        gfinish();
         if constexpr (BF16) {
             __bf16* Ab = Ah + buf * BM * LDH;
             __bf16* Bb = Bh + buf * BN * LDH;
@@ -1799,6 +1817,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     f32x4 ra[SCALAR_A ? 1 : A_V];
     float ras[SCALAR_A ? A_S : 1];
     f32x4 rbv[B_V];
+    // vector paths: the source-mask value travels with its quad and is multiplied in at the LDS store (see igemm_body)
+    float rbm[B_V];
 
     // (b, oy, ox) of the B' rows this thread gathers, for the NEXT K step; advanced by 32 pixels per step
     int pb[B_V], py[B_V], px[B_V];
@@ -1846,12 +1866,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
             for (int i = 0; i < B_V; ++i) {
                 const int ix = ixb + ((tid >> 5) + 8 * i) * p.stride;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                float mk = 1.f;
                 if (vy && ix >= 0 && ix < p.W) {
                     const size_t pix = rowoff + ix;
                     v = *reinterpret_cast<const f32x4*>(p.x + pix * p.C + bc[0]);
-                    if (p.amask) v *= p.amask[pix];
+                    if (p.amask) mk = p.amask[pix];
                 }
                 rbv[i] = v;
+                rbm[i] = mk;
             }
             rs_ox0 += BK;
             if (rs_ox0 >= p.Wo) {
@@ -1865,16 +1887,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
             int krow = (tid >> 5) + 8 * i;
             int m = mbase + krow;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < p.Mpix) {
+            if constexpr (!SCALAR_B) {
                 const int ox = px[i], oy = py[i], b = pb[i];
-                if constexpr (!SCALAR_B) {
-                    int iy = oy * p.stride + bky[0], ix = ox * p.stride + bkx[0];
-                    if (bv[0] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                        size_t pix = ((size_t)b * p.H + iy) * p.W + ix;
-                        v = *reinterpret_cast<const f32x4*>(p.x + pix * p.C + bc[0]);
-                        if (p.amask) v *= p.amask[pix];
-                    }
-                } else {
+                const int iy = oy * p.stride + bky[0], ix = ox * p.stride + bkx[0];
+                float mk = 1.f;
+                if (m < p.Mpix && bv[0] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                    const size_t pix = ((size_t)b * p.H + iy) * p.W + ix;
+                    v = *reinterpret_cast<const f32x4*>(p.x + pix * p.C + bc[0]);
+                    if (p.amask) mk = p.amask[pix];
+                }
+                rbm[i] = mk;
+            } else if (m < p.Mpix) {
+                const int ox = px[i], oy = py[i], b = pb[i];
+                {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         int iy = oy * p.stride + bky[e], ix = ox * p.stride + bkx[e];
@@ -1899,6 +1924,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     auto sstore = [&](int buf) {
         float* Ab = As + buf * BK * BM;
         float* Bb = Bs + buf * BK * BN;
+        if constexpr (!SCALAR_B) {
+            if (p.amask) {
+#pragma unroll
+                for (int i = 0; i < B_V; ++i) rbv[i] *= rbm[i];
+            }
+        }
         if constexpr (!SCALAR_A) {
             constexpr int PER_ROW = BM / 4;
 #pragma unroll

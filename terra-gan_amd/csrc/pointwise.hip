@@ -1150,20 +1150,28 @@ __global__ __launch_bounds__(256) void upcat_bwd_x2_kernel(const float* __restri
                     wx[k] = (l.i0 == x ? l.l0 : 0.f) + (l.i1 == x ? l.l1 : 0.f);
                 }
             }
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // all sixteen quads requested together at clamped coordinates (a weight is zero only on the border, where the clamped
+            // quad is dropped by the select below): with the load inside `if (w != 0)` every quad was awaited by its own FMA before
+            // the next branch could issue -- sixteen round trips in a row per thread
+            f32x4 S[4][4];
 #pragma unroll
             for (int ky = 0; ky < 4; ++ky) {
-                if (wy[ky] == 0.f) continue;
-                const int yu = 2 * y - 1 + ky;
+                const int yu = min(max(2 * y - 1 + ky, 0), H - 1);
 #pragma unroll
                 for (int kx = 0; kx < 4; ++kx) {
-                    if (wx[kx] == 0.f) continue;
-                    const int xu = 2 * x - 1 + kx;
-                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(dout + (((size_t)b * H + yu) * W + xu) * Ct + c);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] = __fmaf_rn(__fmul_rn(wy[ky], wx[kx]), s4[e], acc[e]);
+                    const int xu = min(max(2 * x - 1 + kx, 0), W - 1);
+                    S[ky][kx] = *reinterpret_cast<const f32x4*>(dout + (((size_t)b * H + yu) * W + xu) * Ct + c);
                 }
             }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    const bool on = wy[ky] != 0.f && wx[kx] != 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = on ? __fmaf_rn(__fmul_rn(wy[ky], wx[kx]), S[ky][kx][e], acc[e]) : acc[e];
+                }
             *reinterpret_cast<f32x4*>(dup + (((size_t)b * h + y) * w + x) * Cu + c) = acc;
         } else {
             const uint32_t k = idx - nA;

@@ -206,6 +206,15 @@ int tg_bn_act_bwd(const float* dout, const float* y, int64_t rows, int C, const 
                   const float* rstd, const float* gamma, const float* beta, int act, float slope,
                   const float* ratio, float* dy, float* dgamma, float* dbeta, float* dbias, float* ws,
                   size_t ws_bytes, tg_stream_t stream);
+/* The same when the incoming gradient is the INPUT gradient of a C -> 1 channel 3x3 / stride-1 / pad-1 convolution (dec1's
+ * BatchNorm under `final`, generator.py:29,56 + pconv.py:43-48):  dout[b][y][x][c] = sum_{ky,kx} dz[b][y+1-ky][x+1-kx] * w[ky][kx][c]
+ * (w = that convolution's weight, [1][3][3][C]) is recomputed from the 1-channel dz inside both passes instead of being written by
+ * tg_conv_dgrad and read twice.  dy [B][H][W][C] is written (nothing is consumed in place).  tg_bn_bwd_conv1_supported(rows, C):
+ * C % 4 == 0 and more rows than the one-launch small-map form takes. */
+int tg_bn_bwd_conv1_supported(int64_t rows, int C);
+int tg_bn_act_bwd_conv1(const float* dz, const float* w, int B, int H, int W, const float* y, int C, const float* mean,
+                        const float* rstd, const float* gamma, const float* beta, int act, float slope, const float* ratio,
+                        float* dy, float* dgamma, float* dbeta, float* dbias, float* ws, size_t ws_bytes, tg_stream_t stream);
 /* din = dout * act'(out) [* ratio[row]] for a conv epilogue activation (out = post-activation).
  * din may alias dout. */
 int tg_act_bwd(const float* dout, const float* out, int64_t rows, int C, int act, float slope,

@@ -795,6 +795,169 @@ __global__ __launch_bounds__(256) void bn_bwd_apply1_kernel(const float* __restr
         dy[i] = v;
     }
 }
+// ---- BatchNorm backward whose incoming gradient is the input gradient of a C -> 1 channel 3x3 / stride 1 / pad 1 convolution ----
+// (dec1 under `final`, generator.py:29,56): dout[b][y][x][c] = sum_{ky,kx} dz[b][y+1-ky][x+1-kx] * w[ky][kx][c] costs nine FMAs per
+// element from a 1-channel tensor, so it is RECOMPUTED in both passes (sums, apply) instead of being written once by the dgrad
+// kernel and read twice: per step one 268 MB write and two 268 MB reads less at the headline size.  Same block geometry and
+// partial layout as colreduce4_kernel<5, BnBwdF> (the shared finaliser follows); a block walks a contiguous row range, so the
+// pixel coordinates advance incrementally (one division per thread).
+struct BnConv1 {
+    const float* dz;     // [B][H][W]
+    const float* w;      // [3][3][C]
+    int H, W;
+};
+struct Conv1Walk {
+    int b, y, x;
+    __device__ void init(int64_t r, int H, int W) {
+        x = (int)(r % W);
+        const int64_t t = r / W;
+        y = (int)(t % H);
+        b = (int)(t / H);
+    }
+    __device__ void advance(int step, int H, int W) {
+        x += step;
+        while (x >= W) {
+            x -= W;
+            if (++y == H) { y = 0; ++b; }
+        }
+    }
+};
+__device__ __forceinline__ f32x4 conv1_dgrad_quad(const BnConv1& cv, const Conv1Walk& p, const f32x4 (&wq)[9]) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* img = cv.dz + (size_t)p.b * cv.H * cv.W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = p.y + 1 - ky;
+        const bool vy = yy >= 0 && yy < cv.H;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xx = p.x + 1 - kx;
+            const bool ok = vy && xx >= 0 && xx < cv.W;
+            const float d = img[ok ? yy * cv.W + xx : 0];            // unconditional load at a clamped address
+            const float dd = ok ? d : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(dd, wq[ky * 3 + kx][e], acc[e]);
+        }
+    }
+    return acc;
+}
+__global__ __launch_bounds__(256) void bn_bwd_conv1_reduce_kernel(const BnBwdF f, const BnConv1 cv, int64_t rows, int C, int qpp, int rlanes,
+                                                                  int64_t rows_per_block, float* __restrict__ partial) {
+    __shared__ float red[5][4][256];
+    const int tid = threadIdx.x;
+    const int cq = tid % qpp, rl = tid / qpp;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    const int c0 = cq * 4;                                            // (one column pass: C <= 1024)
+    float q[5][4];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[i][e] = 0.f;
+    const bool on = rl < rlanes && c0 < C;
+    if (on) {
+        f32x4 wq[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wq[t] = *reinterpret_cast<const f32x4*>(cv.w + (size_t)t * C + c0);
+        const f32x4 mv = *reinterpret_cast<const f32x4*>(f.mean + c0), rv = *reinterpret_cast<const f32x4*>(f.rstd + c0);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(f.gamma + c0), bv = *reinterpret_cast<const f32x4*>(f.beta + c0);
+        Conv1Walk p;
+        p.init(r0 + rl, cv.H, cv.W);
+#pragma unroll 2
+        for (int64_t r = r0 + rl; r < r1; r += rlanes) {
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(f.y + r * C + c0);
+            const f32x4 dv = conv1_dgrad_quad(cv, p, wq);
+            const float rr = f.ratio ? f.ratio[r] : 1.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (yv[e] - mv[e]) * rv[e];
+                const float g = dv[e] * act_grad(xh * gv[e] + bv[e], f.act, f.slope);
+                q[0][e] += g;
+                q[1][e] += g * xh;
+                q[2][e] += rr * g;
+                q[3][e] += rr * xh;
+                q[4][e] += rr;
+            }
+            p.advance(rlanes, cv.H, cv.W);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[i][e][tid] = on ? q[i][e] : 0.f;
+    __syncthreads();
+    if (rl == 0 && c0 < C) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sacc = 0.f;
+                for (int l = 0; l < rlanes; ++l) sacc += red[i][e][l * qpp + cq];
+                partial[((size_t)blockIdx.x * 5 + i) * C + c0 + e] = sacc;
+            }
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_conv1_apply_kernel(const BnBwdF f, const BnConv1 cv, int64_t rows, int C, int qpp, int rlanes,
+                                                                 int64_t rows_per_block, const float* __restrict__ dgamma,
+                                                                 const float* __restrict__ dbeta, float* __restrict__ dy) {
+    const int cq = threadIdx.x % qpp, rl = threadIdx.x / qpp;
+    const int c0 = cq * 4;
+    if (rl >= rlanes || c0 >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    const float inv_n = 1.0f / (float)rows;
+    f32x4 wq[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wq[t] = *reinterpret_cast<const f32x4*>(cv.w + (size_t)t * C + c0);
+    const f32x4 mv = *reinterpret_cast<const f32x4*>(f.mean + c0), rv = *reinterpret_cast<const f32x4*>(f.rstd + c0);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(f.gamma + c0), bv = *reinterpret_cast<const f32x4*>(f.beta + c0);
+    const f32x4 dgv = *reinterpret_cast<const f32x4*>(dgamma + c0), dbv = *reinterpret_cast<const f32x4*>(dbeta + c0);
+    Conv1Walk p;
+    p.init(r0 + rl, cv.H, cv.W);
+#pragma unroll 2
+    for (int64_t r = r0 + rl; r < r1; r += rlanes) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(f.y + r * C + c0);
+        const f32x4 dv = conv1_dgrad_quad(cv, p, wq);
+        const float rr = f.ratio ? f.ratio[r] : 1.f;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (yv[e] - mv[e]) * rv[e];
+            const float g = dv[e] * act_grad(xh * gv[e] + bv[e], f.act, f.slope);
+            o[e] = gv[e] * rv[e] * (g - dbv[e] * inv_n - xh * dgv[e] * inv_n) * rr;
+        }
+        *reinterpret_cast<f32x4*>(dy + r * C + c0) = o;
+        p.advance(rlanes, cv.H, cv.W);
+    }
+}
+extern "C" int tg_bn_bwd_conv1_supported(int64_t rows, int C) {
+    return C % 4 == 0 && C >= 4 && C <= 1024 && rows > 0 && !bn_small_ok(rows, C) && !getenv("TG_NO_BN_CONV1") ? 1 : 0;
+}
+extern "C" int tg_bn_act_bwd_conv1(const float* dz, const float* w, int B, int H, int W, const float* y, int C, const float* mean,
+                                   const float* rstd, const float* gamma, const float* beta, int act, float slope, const float* ratio,
+                                   float* dy, float* dgamma, float* dbeta, float* dbias, float* ws, size_t ws_bytes, tg_stream_t stream) {
+    TG_REQUIRE(dz && w && y && mean && rstd && gamma && beta && dy && dgamma && dbeta && ws && B > 0 && H > 0 && W > 0,
+               "tg_bn_act_bwd_conv1: bad arguments");
+    const int64_t rows = (int64_t)B * H * W;
+    TG_REQUIRE(tg_bn_bwd_conv1_supported(rows, C), "tg_bn_act_bwd_conv1: geometry not supported (ask tg_bn_bwd_conv1_supported first)");
+    TG_REQUIRE(ws_bytes >= tg_bn_ws_bytes(rows, C), "tg_bn_act_bwd_conv1: workspace too small");
+    const BnBwdF f{nullptr, y, mean, rstd, gamma, beta, C, act, slope, ratio};
+    const BnConv1 cv{dz, w, H, W};
+    const ColGeom4 g = col_geom4(rows, C);
+    hipLaunchKernelGGL(bn_bwd_conv1_reduce_kernel, dim3(g.grid), dim3(256), 0, S(stream), f, cv, rows, C, g.qpp, g.rlanes, g.rows_per_block, ws);
+    TG_CHECK_LAUNCH("bn_bwd_conv1_reduce_kernel");
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fr_grid(C)), dim3(256), 0, S(stream), ws, g.grid, C, (double)rows, gamma, rstd, dgamma,
+                       dbeta, dbias);
+    TG_CHECK_LAUNCH("bn_bwd_final");
+    // apply: contiguous row ranges per block as well (the coordinates advance incrementally), ~8 blocks per CU
+    int64_t want = cdiv64(rows, (int64_t)g.rlanes * 32);
+    if (want > 2048) want = 2048;
+    if (want < 1) want = 1;
+    const int64_t rpb = cdiv64(rows, want);
+    const int agrid = (int)cdiv64(rows, rpb);
+    hipLaunchKernelGGL(bn_bwd_conv1_apply_kernel, dim3(agrid), dim3(256), 0, S(stream), f, cv, rows, C, g.qpp, g.rlanes, rpb, dgamma, dbeta, dy);
+    TG_CHECK_LAUNCH("bn_bwd_conv1_apply_kernel");
+    return TG_OK;
+}
+
 extern "C" int tg_bn_act_bwd(const float* dout, const float* y, int64_t rows, int C, const float* mean, const float* rstd,
                              const float* gamma, const float* beta, int act, float slope, const float* ratio, float* dy,
                              float* dgamma, float* dbeta, float* dbias, float* ws, size_t ws_bytes, tg_stream_t stream) {

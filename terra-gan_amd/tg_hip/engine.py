@@ -136,15 +136,21 @@ def _notify(on_ready, grads, keys):
             on_ready(k, grads[k])
 
 
-def _pconv_bwd(P, c, da, grads, dx_out=None, want_dx=True, gbuf=None, on_ready=None):
+def _pconv_bwd(P, c, da, grads, dx_out=None, want_dx=True, gbuf=None, on_ready=None, conv1=None):
     """da: grad w.r.t. the layer's ReLU output (consumed in place).  Returns dx (or None).
-    gbuf: {state-dict key: preallocated gradient tensor} (tg_hip.gradbuf) -- written in place when given."""
+    gbuf: {state-dict key: preallocated gradient tensor} (tg_hip.gradbuf) -- written in place when given.
+    conv1 = (dz, w): da is None and stands for conv_dgrad(dz, w) of the C -> 1 channel conv above this layer (`final` over dec1),
+    recomputed inside the BatchNorm backward instead of being materialised (O.bn_act_bwd_conv1)."""
     name = c.name
     if PROBE is not None:
         PROBE("bwd", name, da)
     outs = (gbuf[f"{name}.bn.weight"], gbuf[f"{name}.bn.bias"], gbuf[f"{name}.input_conv.bias"]) if gbuf is not None else None
-    dyr, dgamma, dbeta, db = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU,
-                                          ratio=c.ratio, outs=outs)
+    if conv1 is not None:
+        dyr, dgamma, dbeta, db = O.bn_act_bwd_conv1(conv1[0], conv1[1], c.y, c.mean, c.rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"],
+                                                    O.ACT_RELU, ratio=c.ratio, outs=outs)
+    else:
+        dyr, dgamma, dbeta, db = O.bn_act_bwd(da, c.y, c.mean, c.rstd, P[f"{name}.bn.weight"], P[f"{name}.bn.bias"], O.ACT_RELU,
+                                              ratio=c.ratio, outs=outs)
     # dgrad first: the weight gradient is enqueued behind it on the side stream, so it starts when the dgrad has
     # finished and runs underneath the NEXT layer's BatchNorm-backward reductions (small grids) and its dgrad
     O.tag(f"{name}.dgrad")
@@ -243,6 +249,7 @@ def _bn_in(P, c):
 # an HBM-bound kernel that stages its source through LDS: the affine map + ReLU are applied there and the widest activation of the
 # network (B x H x W x 64) is neither written nor read back (TG_NO_BNIN=1: the two-pass form; same bits either way)
 BNIN_FINAL = os.environ.get("TG_NO_BNIN") is None
+BN_CONV1 = os.environ.get("TG_NO_BN_CONV1") is None        # dec1's BatchNorm backward recomputes `final`'s input gradient (see generator_backward)
 # dec2 ... dec5 the same way into the next level's upsample + concat (TG_NO_BNIN_UPCAT=1 / TG_NO_BNIN=1: off)
 BNIN_UPCAT = os.environ.get("TG_NO_BNIN") is None and os.environ.get("TG_NO_BNIN_UPCAT") is None
 
@@ -261,8 +268,14 @@ def generator_backward(P, ctx, dout, want_dx=False, gbuf=None, on_ready=None):
     bnin = getattr(ctx, "bnin_final", False)
     # (BN-on-load: `final`'s input is dec1's PRE-BatchNorm output + its statistics -- nothing to recompute under checkpointing)
     d0 = ctx.dec[6].y if bnin else (_act_of(P, ctx.dec[6]) if ckpt else ctx.d0)
-    O.tag("final.dgrad")
-    da = O.conv_dgrad(dz, P["final.weight"], tuple(d0.shape), 3, 1, 1)
+    # `final`'s input gradient costs nine FMAs per element from the 1-channel dz: dec1's BatchNorm backward recomputes it in both
+    # of its passes instead of reading a written copy twice (TG_NO_BN_CONV1=1 / a PROBE: the materialised form)
+    fuse1 = BN_CONV1 and PROBE is None and O.bn_bwd_conv1_supported(tuple(d0.shape))
+    if fuse1:
+        da = None
+    else:
+        O.tag("final.dgrad")
+        da = O.conv_dgrad(dz, P["final.weight"], tuple(d0.shape), 3, 1, 1)
     O.tag("final.wgrad")
     grads["final.weight"], grads["final.bias"] = _wgrad(gbuf, (d0, dz), lambda: O.conv_wgrad(
         d0, dz, P["final.weight"], 3, 1, 1, dw_out=gbuf["final.weight"] if gbuf is not None else None,
@@ -282,7 +295,7 @@ def generator_backward(P, ctx, dout, want_dx=False, gbuf=None, on_ready=None):
                 c.x = O.upcat_fwd(up_src, skip, c.skip_hw[0], c.skip_hw[1], out_mask=c.in_mask)
                 del up_src
             del skip
-        dcat = _pconv_bwd(P, c, da, grads, gbuf=gbuf, on_ready=on_ready)
+        dcat = _pconv_bwd(P, c, da, grads, gbuf=gbuf, on_ready=on_ready, conv1=(dz, P["final.weight"]) if (i == 6 and fuse1) else None)
         if ckpt:
             c.x = None
         _b, h, w, Cu = c.up_shape

@@ -73,6 +73,8 @@ SIGNATURES = {
     "tg_bn_act_fwd": (I, [P, I64, I, P, P, P, P, I, F, P, P]),
     "tg_bn_fwd": (I, [P, I64, I, F, F, P, P, I, F, P, P, P, P, P, P, P, SZ, P]),
     "tg_bn_act_bwd": (I, [P, P, I64, I, P, P, P, P, I, F, P, P, P, P, P, P, SZ, P]),
+    "tg_bn_bwd_conv1_supported": (I, [I64, I]),
+    "tg_bn_act_bwd_conv1": (I, [P, P, I, I, I, P, I, P, P, P, P, I, F, P, P, P, P, P, P, SZ, P]),
     "tg_act_bwd": (I, [P, P, I64, I, I, F, P, P, P]),
     "tg_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P]),
     "tg_upcat_bn_supported": (I, [I, I, I, I, I, I, I]),

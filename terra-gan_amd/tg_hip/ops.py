@@ -543,6 +543,36 @@ def bn_act_bwd(dout, y, mean, rstd, gamma, beta, act, slope=0.0, ratio=None, inp
     return dy, dgamma, dbeta, dbias
 
 
+def bn_bwd_conv1_supported(y_shape):
+    Cc = y_shape[-1]
+    rows = 1
+    for d in y_shape[:-1]:
+        rows *= d
+    return bool(_lib().tg_bn_bwd_conv1_supported(rows, Cc))
+
+
+def bn_act_bwd_conv1(dz, w, y, mean, rstd, gamma, beta, act, slope=0.0, ratio=None, want_dbias=True, outs=None):
+    """bn_act_bwd with dout = conv_dgrad(dz, w) of a C -> 1 channel 3x3 / stride-1 / pad-1 conv recomputed on the fly from the
+    1-channel dz ([B][H][W] or [B][H][W][1]); w = that conv's weight.  Returns (dy, dgamma, dbeta, dbias), dy a new tensor."""
+    _chk(dz, "dz"); _chk(y, "y"); _chk(ratio, "ratio")
+    wv = weight_view(w)
+    _chk(wv, "weight")
+    B, H, W, Cc = y.shape
+    assert dz.numel() == B * H * W and tuple(wv.shape) == (1, 3, 3, Cc), (tuple(dz.shape), tuple(wv.shape))
+    dy = torch.empty_like(y)
+    if outs is not None:
+        dgamma, dbeta, dbias = outs
+    else:
+        dgamma, dbeta = empty(Cc, like=y), empty(Cc, like=y)
+        dbias = empty(Cc, like=y) if want_dbias else None
+    lib = _lib()
+    ws = workspace(lib.tg_bn_ws_bytes(B * H * W, Cc))
+    L.check(lib.tg_bn_act_bwd_conv1(_p(dz), _p(wv), B, H, W, _p(y), Cc, _p(mean), _p(rstd), _p(gamma.detach()), _p(beta.detach()), act,
+                                    slope, _p(ratio), _p(dy), _p(dgamma), _p(dbeta), _p(dbias), _p(ws), ws.numel() * 4, _stream()),
+            "tg_bn_act_bwd_conv1")
+    return dy, dgamma, dbeta, dbias
+
+
 def act_bwd(dout, out, act, slope=0.0, ratio=None, inplace=True):
     _chk(dout, "dout"); _chk(out, "out"); _chk(ratio, "ratio")
     Cc = dout.shape[-1]

@@ -402,7 +402,8 @@ def test_generator_with_and_without_bn_on_load(dev):
     x = torch.rand(3, 128, 128, generator=g).to(dev)
     m = (torch.rand(3, 128, 128, generator=g) > 0.3).float().to(dev)
     dout = torch.randn(3, 128, 128, generator=g).to(dev)
-    old = E.BNIN_FINAL, E.BNIN_UPCAT
+    old = E.BNIN_FINAL, E.BNIN_UPCAT, E.BN_CONV1
+    E.BN_CONV1 = False          # (the recomputed-dgrad BatchNorm backward has its own test: it is equal to rounding, not bit for bit)
     try:
         for flag in (True, False):
             E.BNIN_FINAL = E.BNIN_UPCAT = flag          # (dec2 and dec3 have more than 2048 rows here: deferred to their upsample)
@@ -415,7 +416,7 @@ def test_generator_with_and_without_bn_on_load(dev):
             grads, _ = E.generator_backward(P, ctx, dout.clone())
             res.append((out.clone(), {k: v.clone() for k, v in grads.items()}, {k: v.clone() for k, v in G.named_buffers()}))
     finally:
-        E.BNIN_FINAL, E.BNIN_UPCAT = old
+        E.BNIN_FINAL, E.BNIN_UPCAT, E.BN_CONV1 = old
     (o1, g1, b1), (o0, g0, b0) = res
     assert torch.equal(o1, o0)
     for k in g0:
@@ -441,3 +442,38 @@ def test_upcat_bn_on_load_equals_the_two_call_form(dev, shape):
     c0 = O.upcat_fwd(a, skip, 2 * h, 2 * w, out_mask=om)
     c1 = O.upcat_fwd(y, skip, 2 * h, 2 * w, out_mask=om, up_bn=(mean, rstd, gamma, beta, O.ACT_RELU, 0.0))
     assert torch.equal(c0, c1), float((c0 - c1).abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 64), (3, 40, 24, 32), (2, 20, 52, 128), (2, 17, 23, 16)])
+def test_bn_backward_over_a_recomputed_1channel_dgrad(dev, shape):
+    """tg_bn_act_bwd_conv1 (dec1's BatchNorm backward with `final`'s input gradient recomputed from the 1-channel dz in both passes)
+    against tg_conv_dgrad + tg_bn_act_bwd, and both against fp64."""
+    from tg_hip import ops as O
+    B, H, W, Cc = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    y = (torch.randn(B, H, W, Cc, generator=g) * 1.5 + 0.3).to(dev)
+    gamma, beta = (torch.rand(Cc, generator=g) + 0.5).to(dev), (torch.randn(Cc, generator=g) * 0.3).to(dev)
+    ratio = (torch.rand(B, H, W, generator=g) * 2).to(dev)
+    w = (torch.randn(1, Cc, 3, 3, generator=g) * 0.2).contiguous(memory_format=torch.channels_last).to(dev)
+    dz = torch.randn(B, H, W, 1, generator=g).to(dev)
+    mean, rstd = O.bn_stats(y)
+    assert O.bn_bwd_conv1_supported(tuple(y.shape))
+    assert not O.bn_bwd_conv1_supported((1, 16, 64, 128))          # a small map: the one-launch BatchNorm backward keeps it
+    da = O.conv_dgrad(dz, w, tuple(y.shape), 3, 1, 1)
+    dy0, dg0, db0, dbias0 = O.bn_act_bwd(da.clone(), y, mean, rstd, gamma, beta, O.ACT_RELU, ratio=ratio, inplace=False)
+    dy1, dg1, db1, dbias1 = O.bn_act_bwd_conv1(dz, w, y, mean, rstd, gamma, beta, O.ACT_RELU, ratio=ratio)
+    for a, b in ((dy0, dy1), (dg0, dg1), (db0, db1), (dbias0, dbias1)):
+        sc = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 2e-6 * sc + 1e-7, (float((a - b).abs().max()), sc)
+    # fp64 reference of the whole chain
+    yd, m64, r64 = y.double().cpu(), mean.double().cpu(), rstd.double().cpu()
+    dad = F.conv_transpose2d(nchw(dz.double().cpu()), w.double().cpu(), None, 1, 1).permute(0, 2, 3, 1)
+    xh = (yd - m64) * r64
+    gg = dad * ((xh * gamma.double().cpu() + beta.double().cpu()) > 0)
+    n = B * H * W
+    dbeta, dgamma = gg.sum((0, 1, 2)), (gg * xh).sum((0, 1, 2))
+    dyr = gamma.double().cpu() * r64 * (gg - dbeta / n - xh * dgamma / n) * ratio.double().cpu()[..., None]
+    close(dy1, dyr, rtol=1e-4, atol=1e-5 * float(dyr.abs().max()))
+    close(dg1, dgamma, rtol=1e-4, atol=1e-5 * float(dgamma.abs().max()))
+    close(db1, dbeta, rtol=1e-4, atol=1e-5 * float(dbeta.abs().max()))
+    close(dbias1, dyr.sum((0, 1, 2)), rtol=1e-4, atol=2e-5 * float(dyr.abs().sum((0, 1, 2)).max()))

@@ -466,9 +466,10 @@ def test_config5_fullsize_checkpointed_step(dev):
     """BASELINE config 5's per-GPU shape -- 1024x1024, batch 4, activation checkpointing -- through size-independent
     properties (the CPU oracle would need ~10 minutes here): the checkpointed step is bit-identical to the plain one
     (losses, generator output, every weight after two Adam steps), bitwise reproducible run to run, valid pixels are
-    copied exactly (generator.py:60-62), and the peak HBM footprint drops (by the generator's post-activation and concat
-    tensors, ~2 GiB of ~15 here: the VGG trunk's activations of the 2 x 4 perceptual-loss images dominate the peak and are
-    not checkpointed)."""
+    copied exactly (generator.py:60-62), and the peak HBM footprint drops by the generator's encoder activations and concat
+    tensors -- ~1 GiB of ~13.6 here (2 of 15 before round 4: the PLAIN step no longer writes the decoder's post-activation tensors
+    either, its BatchNorm + ReLU are applied on load); the VGG trunk's activations of the 2 x 4 perceptual-loss images dominate
+    the peak and are not checkpointed."""
     from mvp_gan.src.train import train_step
     from oracle import terragan_oracle as Orc
     real, mask = Orc.synth_batch(4, 1024, 3001)
@@ -497,7 +498,7 @@ def test_config5_fullsize_checkpointed_step(dev):
     valid = mask > 0
     assert torch.equal(gen[valid], (real * mask)[valid]) and bool(torch.isfinite(gen).all())
     print(f"\nconfig 5 peak HBM over the step: plain {res['plain'][4] / 2**30:.2f} GiB, checkpointed {res['ckpt'][4] / 2**30:.2f} GiB")
-    assert res["ckpt"][4] < res["plain"][4] - (1 << 30), (res["plain"][4], res["ckpt"][4])      # at least 1 GiB less
+    assert res["ckpt"][4] < res["plain"][4] - (3 << 28), (res["plain"][4], res["ckpt"][4])      # at least 0.75 GiB less
 
 
 def test_adam_state_from_reference_format_checkpoint(dev):

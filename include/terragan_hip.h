@@ -212,6 +212,7 @@ int tg_bn_act_bwd(const float* dout, const float* y, int64_t rows, int C, const 
  * tg_conv_dgrad and read twice.  dy [B][H][W][C] is written (nothing is consumed in place).  tg_bn_bwd_conv1_supported(rows, C):
  * C % 4 == 0 and more rows than the one-launch small-map form takes. */
 int tg_bn_bwd_conv1_supported(int64_t rows, int C);
+size_t tg_bn_conv1_ws_bytes(int64_t rows, int C);
 int tg_bn_act_bwd_conv1(const float* dz, const float* w, int B, int H, int W, const float* y, int C, const float* mean,
                         const float* rstd, const float* gamma, const float* beta, int act, float slope, const float* ratio,
                         float* dy, float* dgamma, float* dbeta, float* dbias, float* ws, size_t ws_bytes, tg_stream_t stream);

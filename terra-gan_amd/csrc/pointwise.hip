@@ -822,6 +822,24 @@ struct Conv1Walk {
         }
     }
 };
+// SHARE form (qpp = 16 / 32 / 64 channel quads: the threads of a pixel are an aligned lane group of that width): lane t < 9 of the
+// group fetches tap t -- one address, one bounds test, one load per thread and row instead of nine of each, all sixteen-fold
+// redundant -- and the nine words go round by ds_bpermute (`__shfl` inside the group).  The vector ALU, not HBM, bounded the
+// first form: ~180 instructions per thread and row, half of them tap addressing.
+__device__ __forceinline__ f32x4 conv1_dgrad_quad_shared(const BnConv1& cv, const Conv1Walk& p, const f32x4 (&wq)[9], int ky, int kx, int width) {
+    const int yy = p.y + 1 - ky, xx = p.x + 1 - kx;
+    const bool ok = yy >= 0 && yy < cv.H && xx >= 0 && xx < cv.W;
+    const float d = cv.dz[(size_t)p.b * cv.H * cv.W + (ok ? yy * cv.W + xx : 0)];
+    const float mine = ok ? d : 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float dd = __shfl(mine, t, width);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(dd, wq[t][e], acc[e]);
+    }
+    return acc;
+}
 __device__ __forceinline__ f32x4 conv1_dgrad_quad(const BnConv1& cv, const Conv1Walk& p, const f32x4 (&wq)[9]) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float* img = cv.dz + (size_t)p.b * cv.H * cv.W;
@@ -841,6 +859,7 @@ __device__ __forceinline__ f32x4 conv1_dgrad_quad(const BnConv1& cv, const Conv1
     }
     return acc;
 }
+template <bool SHARE>
 __global__ __launch_bounds__(256) void bn_bwd_conv1_reduce_kernel(const BnBwdF f, const BnConv1 cv, int64_t rows, int C, int qpp, int rlanes,
                                                                   int64_t rows_per_block, float* __restrict__ partial) {
     __shared__ float red[5][4][256];
@@ -862,10 +881,11 @@ __global__ __launch_bounds__(256) void bn_bwd_conv1_reduce_kernel(const BnBwdF f
         const f32x4 gv = *reinterpret_cast<const f32x4*>(f.gamma + c0), bv = *reinterpret_cast<const f32x4*>(f.beta + c0);
         Conv1Walk p;
         p.init(r0 + rl, cv.H, cv.W);
-#pragma unroll 2
+        const int my_t = cq < 9 ? cq : 0, my_ky = my_t / 3, my_kx = my_t - 3 * my_ky;
+#pragma unroll 4
         for (int64_t r = r0 + rl; r < r1; r += rlanes) {
             const f32x4 yv = *reinterpret_cast<const f32x4*>(f.y + r * C + c0);
-            const f32x4 dv = conv1_dgrad_quad(cv, p, wq);
+            const f32x4 dv = SHARE ? conv1_dgrad_quad_shared(cv, p, wq, my_ky, my_kx, qpp) : conv1_dgrad_quad(cv, p, wq);
             const float rr = f.ratio ? f.ratio[r] : 1.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -896,6 +916,7 @@ __global__ __launch_bounds__(256) void bn_bwd_conv1_reduce_kernel(const BnBwdF f
             }
     }
 }
+template <bool SHARE>
 __global__ __launch_bounds__(256) void bn_bwd_conv1_apply_kernel(const BnBwdF f, const BnConv1 cv, int64_t rows, int C, int qpp, int rlanes,
                                                                  int64_t rows_per_block, const float* __restrict__ dgamma,
                                                                  const float* __restrict__ dbeta, float* __restrict__ dy) {
@@ -912,10 +933,11 @@ __global__ __launch_bounds__(256) void bn_bwd_conv1_apply_kernel(const BnBwdF f,
     const f32x4 dgv = *reinterpret_cast<const f32x4*>(dgamma + c0), dbv = *reinterpret_cast<const f32x4*>(dbeta + c0);
     Conv1Walk p;
     p.init(r0 + rl, cv.H, cv.W);
+    const int my_t = cq < 9 ? cq : 0, my_ky = my_t / 3, my_kx = my_t - 3 * my_ky;
 #pragma unroll 2
     for (int64_t r = r0 + rl; r < r1; r += rlanes) {
         const f32x4 yv = *reinterpret_cast<const f32x4*>(f.y + r * C + c0);
-        const f32x4 dv = conv1_dgrad_quad(cv, p, wq);
+        const f32x4 dv = SHARE ? conv1_dgrad_quad_shared(cv, p, wq, my_ky, my_kx, qpp) : conv1_dgrad_quad(cv, p, wq);
         const float rr = f.ratio ? f.ratio[r] : 1.f;
         f32x4 o;
 #pragma unroll
@@ -928,6 +950,10 @@ __global__ __launch_bounds__(256) void bn_bwd_conv1_apply_kernel(const BnBwdF f,
         p.advance(rlanes, cv.H, cv.W);
     }
 }
+extern "C" size_t tg_bn_conv1_ws_bytes(int64_t rows, int C) {
+    const size_t a = tg_bn_ws_bytes(rows, C), b = align_up((size_t)4096 * 5 * C, 64) * sizeof(float);      // up to 4096 first-stage blocks
+    return a > b ? a : b;
+}
 extern "C" int tg_bn_bwd_conv1_supported(int64_t rows, int C) {
     return C % 4 == 0 && C >= 4 && C <= 1024 && rows > 0 && !bn_small_ok(rows, C) && !getenv("TG_NO_BN_CONV1") ? 1 : 0;
 }
@@ -938,11 +964,27 @@ extern "C" int tg_bn_act_bwd_conv1(const float* dz, const float* w, int B, int H
                "tg_bn_act_bwd_conv1: bad arguments");
     const int64_t rows = (int64_t)B * H * W;
     TG_REQUIRE(tg_bn_bwd_conv1_supported(rows, C), "tg_bn_act_bwd_conv1: geometry not supported (ask tg_bn_bwd_conv1_supported first)");
-    TG_REQUIRE(ws_bytes >= tg_bn_ws_bytes(rows, C), "tg_bn_act_bwd_conv1: workspace too small");
+    TG_REQUIRE(ws_bytes >= tg_bn_conv1_ws_bytes(rows, C), "tg_bn_act_bwd_conv1: workspace too small");
     const BnBwdF f{nullptr, y, mean, rstd, gamma, beta, C, act, slope, ratio};
     const BnConv1 cv{dz, w, H, W};
-    const ColGeom4 g = col_geom4(rows, C);
-    hipLaunchKernelGGL(bn_bwd_conv1_reduce_kernel, dim3(g.grid), dim3(256), 0, S(stream), f, cv, rows, C, g.qpp, g.rlanes, g.rows_per_block, ws);
+    ColGeom4 g = col_geom4(rows, C);
+    {
+        // more, shorter blocks than the plain reduction takes: this first stage is arithmetic (nine FMAs + the BatchNorm algebra per
+        // element) behind dependent loads, two waves per SIMD cannot hide them
+        static const int cgrid_env = getenv("TG_BN_CONV1_GRID") ? atoi(getenv("TG_BN_CONV1_GRID")) : 2048;
+        const int cgrid = cgrid_env < 1 ? 1 : (cgrid_env > 4096 ? 4096 : cgrid_env);
+        int64_t want = cdiv64(rows, (int64_t)g.rlanes * 8);
+        if (want > cgrid) want = cgrid;
+        if (want < 1) want = 1;
+        g.rows_per_block = cdiv64(rows, want);
+        g.grid = (int)cdiv64(rows, g.rows_per_block);
+    }
+    // lane-group sharing of the nine taps: the threads of a pixel must be a whole, aligned power-of-two set of lanes of ONE wave
+    // (qpp = 16 / 32 / 64); they share the row index, hence every loop trip and the early exits -- a group is never partly active
+    static const bool no_share = getenv("TG_BN_CONV1_NO_SHARE") != nullptr;
+    const bool share = !no_share && (g.qpp == 16 || g.qpp == 32 || g.qpp == 64);
+    if (share) hipLaunchKernelGGL(bn_bwd_conv1_reduce_kernel<true>, dim3(g.grid), dim3(256), 0, S(stream), f, cv, rows, C, g.qpp, g.rlanes, g.rows_per_block, ws);
+    else hipLaunchKernelGGL(bn_bwd_conv1_reduce_kernel<false>, dim3(g.grid), dim3(256), 0, S(stream), f, cv, rows, C, g.qpp, g.rlanes, g.rows_per_block, ws);
     TG_CHECK_LAUNCH("bn_bwd_conv1_reduce_kernel");
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fr_grid(C)), dim3(256), 0, S(stream), ws, g.grid, C, (double)rows, gamma, rstd, dgamma,
                        dbeta, dbias);
@@ -953,7 +995,8 @@ extern "C" int tg_bn_act_bwd_conv1(const float* dz, const float* w, int B, int H
     if (want < 1) want = 1;
     const int64_t rpb = cdiv64(rows, want);
     const int agrid = (int)cdiv64(rows, rpb);
-    hipLaunchKernelGGL(bn_bwd_conv1_apply_kernel, dim3(agrid), dim3(256), 0, S(stream), f, cv, rows, C, g.qpp, g.rlanes, rpb, dgamma, dbeta, dy);
+    if (share) hipLaunchKernelGGL(bn_bwd_conv1_apply_kernel<true>, dim3(agrid), dim3(256), 0, S(stream), f, cv, rows, C, g.qpp, g.rlanes, rpb, dgamma, dbeta, dy);
+    else hipLaunchKernelGGL(bn_bwd_conv1_apply_kernel<false>, dim3(agrid), dim3(256), 0, S(stream), f, cv, rows, C, g.qpp, g.rlanes, rpb, dgamma, dbeta, dy);
     TG_CHECK_LAUNCH("bn_bwd_conv1_apply_kernel");
     return TG_OK;
 }

@@ -74,6 +74,7 @@ SIGNATURES = {
     "tg_bn_fwd": (I, [P, I64, I, F, F, P, P, I, F, P, P, P, P, P, P, P, SZ, P]),
     "tg_bn_act_bwd": (I, [P, P, I64, I, P, P, P, P, I, F, P, P, P, P, P, P, SZ, P]),
     "tg_bn_bwd_conv1_supported": (I, [I64, I]),
+    "tg_bn_conv1_ws_bytes": (SZ, [I64, I]),
     "tg_bn_act_bwd_conv1": (I, [P, P, I, I, I, P, I, P, P, P, P, I, F, P, P, P, P, P, P, SZ, P]),
     "tg_act_bwd": (I, [P, P, I64, I, I, F, P, P, P]),
     "tg_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P]),

@@ -566,7 +566,7 @@ def bn_act_bwd_conv1(dz, w, y, mean, rstd, gamma, beta, act, slope=0.0, ratio=No
         dgamma, dbeta = empty(Cc, like=y), empty(Cc, like=y)
         dbias = empty(Cc, like=y) if want_dbias else None
     lib = _lib()
-    ws = workspace(lib.tg_bn_ws_bytes(B * H * W, Cc))
+    ws = workspace(lib.tg_bn_conv1_ws_bytes(B * H * W, Cc))
     L.check(lib.tg_bn_act_bwd_conv1(_p(dz), _p(wv), B, H, W, _p(y), Cc, _p(mean), _p(rstd), _p(gamma.detach()), _p(beta.detach()), act,
                                     slope, _p(ratio), _p(dy), _p(dgamma), _p(dbeta), _p(dbias), _p(ws), ws.numel() * 4, _stream()),
             "tg_bn_act_bwd_conv1")

@@ -610,9 +610,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IGemmParams p) {
 // Up to 4 independent problems of one tile configuration in ONE launch (IGemmMulti; the parity classes of a stride-2 dgrad on a
 // small grid: four 17-us launches + four split-K epilogues per layer were pure launch latency): blockIdx.z = class * splits + split.
 template <int WAVES_M, int WAVES_N, int WM, int WN, bool BF16>
-__global__ __launch_bounds__(256, 2) void igemm_multi_kernel(const IGemmMulti pm, const int splits) {
-    const int cls = blockIdx.z / splits;
-    igemm_body<WAVES_M, WAVES_N, WM, WN, false, BF16>(pm.c[cls], blockIdx.z - cls * splits);
+__global__ __launch_bounds__(256, 2) void igemm_multi_kernel(const IGemmMulti pm) {
+    int cls = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) cls += (int)blockIdx.z >= pm.zbeg[i] ? 1 : 0;
+    igemm_body<WAVES_M, WAVES_N, WM, WN, false, BF16>(pm.c[cls], blockIdx.z - pm.zbeg[cls]);
 }
 
 // split-K second pass: fixed-order sum over the slabs + the same epilogue.
@@ -657,7 +659,10 @@ __device__ __forceinline__ void splitk_epilogue_body(const IGemmParams& p) {
 }
 
 __global__ __launch_bounds__(256) void igemm_splitk_epilogue(const IGemmParams p) { splitk_epilogue_body(p); }
-__global__ __launch_bounds__(256) void igemm_splitk_epilogue_multi(const IGemmMulti pm) { splitk_epilogue_body(pm.c[blockIdx.y]); }
+// (a class left at one split has written dst, epilogue applied, from the main kernel: nothing to do for it here)
+__global__ __launch_bounds__(256) void igemm_splitk_epilogue_multi(const IGemmMulti pm) {
+    if (pm.c[blockIdx.y].splits > 1) splitk_epilogue_body(pm.c[blockIdx.y]);
+}
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, bool SCALAR, bool BF16 = false>
 static int launch_igemm_cfg(const IGemmParams& p, hipStream_t s) {
@@ -1134,7 +1139,7 @@ static int launch_igemm(IGemmParams& p, hipStream_t s, size_t ws_floats_avail = 
 // launch + ONE split-K epilogue launch.  All classes share the tile configuration and the split count; a class with fewer K
 // steps than splits leaves its surplus slabs zero.  Returns false when the classes do not qualify (caller goes class by class).
 template <int WAVES_M, int WAVES_N, int WM, int WN, bool BF16>
-static int launch_igemm_multi_cfg(const IGemmMulti& pm, int ncls, int splits, hipStream_t s) {
+static int launch_igemm_multi_cfg(const IGemmMulti& pm, int ncls, hipStream_t s) {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
     constexpr size_t lds = (size_t)2 * (BM + BN) * (BF16 ? 40 * 2 : 36 * sizeof(float));
     static LdsOptIn opt;
@@ -1149,10 +1154,12 @@ static int launch_igemm_multi_cfg(const IGemmMulti& pm, int ncls, int splits, hi
         by += 4.0 * ((double)p.M + (double)p.N * p.Ktot + (double)p.M * p.N);
     }
     by += 4.0 * (double)pm.c[0].B * pm.c[0].IH * pm.c[0].IW * pm.c[0].C;
-    dim3 grid(cdiv(mmax, BM), cdiv(pm.c[0].N, BN), ncls * splits);
+    int splits = 1;
+    for (int i = 0; i < ncls; ++i) splits = pm.c[i].splits > splits ? pm.c[i].splits : splits;
+    dim3 grid(cdiv(mmax, BM), cdiv(pm.c[0].N, BN), pm.zbeg[ncls]);
     {
         ProfScope ps(s, BF16 ? 3 : 0, flops, by, mmax * ncls, pm.c[0].N, pm.c[0].Ktot, pm.c[0].C, splits, (BF16 ? 3000 : 0) + 500 + BN);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, pm, splits);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, pm);
     }
     TG_CHECK_LAUNCH("igemm_multi_kernel");
     if (splits > 1) {
@@ -1182,19 +1189,57 @@ static bool try_igemm_multi(IGemmParams* cls, int ncls, float* ws, size_t ws_flo
         while (smax > 1 && (size_t)smax * mn > ws_floats) --smax;
         splits = choose_splits(tiles, smax, 512);
     }
+    // Split counts PER CLASS.  The parity classes of a 3x3 stride-2 dgrad walk 4, 2, 2 and 1 taps: with one split count for all, the
+    // workgroups of the 1-tap class are done in a quarter of the time of the 4-tap class and their slots idle (enc4's dgrad: 512
+    // resident workgroups, launch time = the 4-tap class's K walk).  Choose a common walk LENGTH L instead, s_i = ceil(T_i / L),
+    // minimising rounds x (longest walk + ~4 steps of prologue / epilogue).
+    int sp[4] = {splits, splits, splits, splits};
+    static const bool uniform = getenv("TG_MULTI_UNIFORM_SPLITS") != nullptr;
+    if (!uniform && tmax >= 8) {
+        long tl[4];
+        for (int i = 0; i < ncls; ++i) tl[i] = (long)cdiv(cls[i].M, 128) * cdiv(cls[i].N, bn);
+        double best = 1e300;
+        for (int L = tmax; L >= 4; --L) {
+            long blocks = 0;
+            int longest = 0, cand[4];
+            size_t need = 0;
+            for (int i = 0; i < ncls; ++i) {
+                int si = cdiv(cls[i].T, L);
+                const int cap = cls[i].T / 4 < 1 ? 1 : (cls[i].T / 4 < 64 ? cls[i].T / 4 : 64);
+                if (si > cap) si = cap;
+                cand[i] = si;
+                blocks += tl[i] * si;
+                const int walk = cdiv(cls[i].T, si);
+                longest = walk > longest ? walk : longest;
+                need += (size_t)si * cls[i].M * cls[i].N;
+            }
+            if (need > ws_floats) break;
+            const long rounds = (blocks + 511) / 512;
+            const double cost = (double)rounds * (longest + 4.0) + 0.002 * (double)blocks;
+            if (cost < best * 0.995) {
+                best = cost;
+                for (int i = 0; i < ncls; ++i) sp[i] = cand[i];
+            }
+        }
+    }
     IGemmMulti pm = {};
     size_t off_f = 0;
     for (int i = 0; i < ncls; ++i) {
         IGemmParams& p = cls[i];
-        p.steps_per_split = cdiv(p.T, splits);
-        p.splits = splits;
+        p.steps_per_split = cdiv(p.T, sp[i]);
+        p.splits = cdiv(p.T, p.steps_per_split);          // (no empty trailing split)
         p.ws = ws + off_f;
-        off_f += (size_t)splits * p.M * p.N;
+        off_f += (size_t)p.splits * p.M * p.N;
+        pm.zbeg[i] = i == 0 ? 0 : pm.zbeg[i - 1] + cls[i - 1].splits;
         pm.c[i] = p;
     }
-    for (int i = ncls; i < 4; ++i) pm.c[i] = pm.c[0];
-    if (cls[0].bf16) *rc = bn == 128 ? launch_igemm_multi_cfg<2, 2, 2, 2, true>(pm, ncls, splits, s) : launch_igemm_multi_cfg<2, 2, 2, 1, true>(pm, ncls, splits, s);
-    else *rc = bn == 128 ? launch_igemm_multi_cfg<2, 2, 2, 2, false>(pm, ncls, splits, s) : launch_igemm_multi_cfg<2, 2, 2, 1, false>(pm, ncls, splits, s);
+    pm.zbeg[ncls] = pm.zbeg[ncls - 1] + cls[ncls - 1].splits;
+    for (int i = ncls; i < 4; ++i) {
+        pm.c[i] = pm.c[0];
+        pm.zbeg[i + 1] = pm.zbeg[ncls];
+    }
+    if (cls[0].bf16) *rc = bn == 128 ? launch_igemm_multi_cfg<2, 2, 2, 2, true>(pm, ncls, s) : launch_igemm_multi_cfg<2, 2, 2, 1, true>(pm, ncls, s);
+    else *rc = bn == 128 ? launch_igemm_multi_cfg<2, 2, 2, 2, false>(pm, ncls, s) : launch_igemm_multi_cfg<2, 2, 2, 1, false>(pm, ncls, s);
     return true;
 }
 

@@ -53,6 +53,7 @@ __device__ __forceinline__ float gate_factor(const IGemmParams& p, size_t idx) {
 // Up to 4 independent problems in ONE launch (the parity classes of a stride-2 dgrad)
 struct IGemmMulti {
     IGemmParams c[4];
+    int zbeg[5];            // igemm_multi_kernel: class i owns blockIdx.z in [zbeg[i], zbeg[i + 1]) -- its own split count (c[i].splits)
 };
 
 struct WgradParams {

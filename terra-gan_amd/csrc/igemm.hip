@@ -2387,13 +2387,14 @@ static int conv_wgrad_impl(const TgConv* g, const float* x, const float* in_mask
         TG_REQUIRE(smallconv_wgrad_applies(p) && smallconv_bnin_wgrad_ok(p), "tg_conv_wgrad_bnin: geometry not supported");
     }
     if (smallconv_wgrad_applies(p)) {
+        int db_done = 0;
         {
             const double by = 4.0 * ((double)p.B * p.H * p.W * p.C + (double)p.Mpix * p.Cout + (double)p.Cout * p.Ktot);
             ProfScope ps(s, 2, 2.0 * p.Mpix * (double)p.Cout * p.Ktot, by, p.Cout, p.Ktot, p.Mpix, p.C, 1, 2001);
-            rc = smallconv_wgrad_launch(p, dw, ws, s);
+            rc = smallconv_wgrad_launch(p, dw, ws, s, db, &db_done);
         }
         if (rc) return rc;
-        if (db) {
+        if (db && !db_done) {
             size_t used = align_up(smallconv_wgrad_ws_floats(p), 64);
             rc = tg_colsum_launch(dy, (int64_t)p.Mpix, g->Cout, db, ws + used, s);
             if (rc) return rc;

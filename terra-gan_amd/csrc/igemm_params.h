@@ -77,4 +77,4 @@ bool smallconv_wgrad_applies(const WgradParams& p);
 bool smallconv_bnin_fwd_ok(const IGemmParams& p);             // launches that can take IGemmParams::in_bn / WgradParams::in_bn
 bool smallconv_bnin_wgrad_ok(const WgradParams& p);
 size_t smallconv_wgrad_ws_floats(const WgradParams& p);
-int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream_t s);
+int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream_t s, float* db = nullptr, int* db_done = nullptr);

@@ -644,9 +644,14 @@ __global__ __launch_bounds__(256) void c1wgrad_kernel(const WgradParams p, const
 // lane = tap, lane half = one of the step's two pixels).  The scalar-gather path of the generic wgrad kernel ran this at
 // 0.7 TB/s (enc1: 113 us for 67 MB of dy; D conv0: 140 us for 134 MB).  Persistent workgroups over 16x16 output tiles,
 // 4 waves x 64 pixels each; partial[block][co][tap], reduced by smallconv_slab_reduce in fixed order (deterministic).
+// The tap tiles are padded to 32 columns and column NT is free for every kernel size here (9, 16, 49): its B operand is the
+// constant 1, so the same MFMAs leave sum_pix dy[pix][co] -- the conv BIAS gradient -- in it (partial_db[block][co]; D conv0's
+// bias gradient was a separate column-sum pass over the same 67 / 134 MB of dy).
 template <int K>
-__global__ __launch_bounds__(256) void c1wgrad_mfma_kernel(const WgradParams p, const C1Geom q, int ntiles, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void c1wgrad_mfma_kernel(const WgradParams p, const C1Geom q, int ntiles, float* __restrict__ partial,
+                                                           float* __restrict__ partial_db) {
     constexpr int NT = K * K, NTT = (NT + 31) / 32;
+    static_assert(NT < NTT * 32, "no free column for the bias sum");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* patch = sm;                                  // [PH*PW]
     float* red = sm + ((q.PH * q.PW + 3) & ~3);         // [64][NTT*32]
@@ -655,10 +660,12 @@ __global__ __launch_bounds__(256) void c1wgrad_mfma_kernel(const WgradParams p, 
     const int co0 = blockIdx.y * 64;
     int tapoff[NTT];
     bool tapok[NTT];
+    float tapfill[NTT];          // B value of a column without a tap: 1 in the bias column, 0 elsewhere
 #pragma unroll
     for (int t = 0; t < NTT; ++t) {
         const int tap = 32 * t + li;
         tapok[t] = tap < NT;
+        tapfill[t] = tap == NT ? 1.f : 0.f;
         const int tt = tapok[t] ? tap : 0;
         tapoff[t] = (tt / K) * q.PW + (tt % K);
     }
@@ -714,7 +721,7 @@ __global__ __launch_bounds__(256) void c1wgrad_mfma_kernel(const WgradParams p, 
                 const int ty_o = wave * 4 + (s >> 3), tx_o = ((2 * s) & 15) + h;
                 const int pbase = ty_o * p.stride * q.PW + tx_o * p.stride;
 #pragma unroll
-                for (int t = 0; t < NTT; ++t) bv[u][t] = tapok[t] ? patch[pbase + tapoff[t]] : 0.f;
+                for (int t = 0; t < NTT; ++t) bv[u][t] = tapok[t] ? patch[pbase + tapoff[t]] : tapfill[t];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -746,6 +753,7 @@ __global__ __launch_bounds__(256) void c1wgrad_mfma_kernel(const WgradParams p, 
         const int co = i / NT, tap = i - co * NT;
         partial[((size_t)blockIdx.x * p.Cout + co0 + co) * NT + tap] = red[co * RP + tap];
     }
+    if (partial_db && threadIdx.x < 64) partial_db[(size_t)blockIdx.x * p.Cout + co0 + threadIdx.x] = red[threadIdx.x * RP + NT];
 }
 
 // Cout == 1, C == 64: dW[tap][c] = sum_pix dy[pix] * x[pix@tap][c]; lane = (pixel of a 4-pixel row segment, channel quad)
@@ -1008,9 +1016,12 @@ bool smallconv_wgrad_applies(const WgradParams& p) {
 size_t smallconv_wgrad_ws_floats(const WgradParams& p) {
     if (to1w_wgrad_ok(p)) return (size_t)p.B * cdiv(p.Ho, 4) * p.k * p.k * p.C + 64;
     const int blocks = p.C == 1 ? c1_wgrad_blocks(p) : (to1_wgrad_lds_ok(p) ? 768 : to1_wgrad_blocks(p));
-    return (size_t)blocks * p.Cout * p.k * p.k * p.C + 64;
+    return (size_t)blocks * p.Cout * p.k * p.k * p.C + (p.C == 1 ? (size_t)blocks * p.Cout : 0) + 64;     // (+ bias partials)
 }
-int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream_t s) {
+// db != nullptr: the launch may produce the bias gradient as well (*db_done = 1: the caller skips its column-sum pass)
+int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream_t s, float* db, int* db_done) {
+    if (db_done) *db_done = 0;
+    float* pdb = nullptr;
     TG_REQUIRE(!p.in_bn.mean || smallconv_bnin_wgrad_ok(p), "smallconv: BatchNorm-on-load is not available for this geometry");
     int nb;
     if (p.C == 1) {
@@ -1025,9 +1036,11 @@ int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream
         if (!getenv("TG_C1WGRAD")) {                 // default: the MFMA kernel
             const int ntt = (p.k * p.k + 31) / 32;
             const size_t lds = (((size_t)q.PH * q.PW + 3) / 4 * 4 + (size_t)64 * (ntt * 32 + 1)) * sizeof(float);
-            if (p.k == 7) hipLaunchKernelGGL((c1wgrad_mfma_kernel<7>), grid, dim3(256), lds, s, p, q, ntiles, ws);
-            else if (p.k == 4) hipLaunchKernelGGL((c1wgrad_mfma_kernel<4>), grid, dim3(256), lds, s, p, q, ntiles, ws);
-            else hipLaunchKernelGGL((c1wgrad_mfma_kernel<3>), grid, dim3(256), lds, s, p, q, ntiles, ws);
+            static const bool no_db = getenv("TG_NO_C1WGRAD_BIAS") != nullptr;
+            if (db && !no_db) pdb = ws + (size_t)nb * p.Cout * p.k * p.k * p.C;
+            if (p.k == 7) hipLaunchKernelGGL((c1wgrad_mfma_kernel<7>), grid, dim3(256), lds, s, p, q, ntiles, ws, pdb);
+            else if (p.k == 4) hipLaunchKernelGGL((c1wgrad_mfma_kernel<4>), grid, dim3(256), lds, s, p, q, ntiles, ws, pdb);
+            else hipLaunchKernelGGL((c1wgrad_mfma_kernel<3>), grid, dim3(256), lds, s, p, q, ntiles, ws, pdb);
             TG_CHECK_LAUNCH("c1wgrad_mfma_kernel");
         } else {
         const size_t lds = (((size_t)q.PH * q.PW + 3) / 4 * 4 + (size_t)4 * p.k * 64) * sizeof(float);
@@ -1060,5 +1073,10 @@ int smallconv_wgrad_launch(const WgradParams& p, float* dw, float* ws, hipStream
     const size_t n = (size_t)p.Cout * p.k * p.k * p.C;
     hipLaunchKernelGGL(smallconv_slab_reduce, dim3((unsigned)cdiv64((int64_t)n, 4)), dim3(256), 0, s, ws, dw, n, nb);
     TG_CHECK_LAUNCH("smallconv_slab_reduce");
+    if (pdb) {
+        hipLaunchKernelGGL(smallconv_slab_reduce, dim3((unsigned)cdiv(p.Cout, 4)), dim3(256), 0, s, pdb, db, (size_t)p.Cout, nb);
+        TG_CHECK_LAUNCH("smallconv_slab_reduce (bias)");
+        if (db_done) *db_done = 1;
+    }
     return TG_OK;
 }

@@ -637,7 +637,16 @@ __device__ __forceinline__ void splitk_epilogue_body(const IGemmParams& p) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v += t[u];
             }
-            for (; z < p.splits; ++z) v += *reinterpret_cast<const f32x4*>(wp + (size_t)z * total);
+            if (z < p.splits) {
+                // the last (or only) group: up to seven slabs, again all in flight (clamped index + select: a rolled tail waits
+                // for one slab after the other, and the per-class split plans of the merged dgrads have 2 ... 7 slabs)
+                f32x4 t[7];
+#pragma unroll
+                for (int u = 0; u < 7; ++u) t[u] = *reinterpret_cast<const f32x4*>(wp + (size_t)(z + u < p.splits ? z + u : z) * total);
+#pragma unroll
+                for (int u = 0; u < 7; ++u)
+                    if (z + u < p.splits) v += t[u];
+            }
             const size_t pix = dst_pixel(p, m);
             *reinterpret_cast<f32x4*>(p.dst + pix * p.N + n) = epilogue4(p, v, pix, n);
         }

@@ -306,13 +306,29 @@ __device__ __forceinline__ void mask_update_one(const float* __restrict__ mask, 
                                                 int Wo, int b, int idx, float* __restrict__ mask_out, float* __restrict__ ratio) {
     const int ox = idx % Wo, oy = idx / Wo;
     float s = 0.f;
-    for (int ky = 0; ky < k; ++ky) {
-        const int iy = oy * stride - pad + ky;
-        if (iy < 0 || iy >= H) continue;
-        for (int kx = 0; kx < k; ++kx) {
-            const int ix = ox * stride - pad + kx;
-            if (ix < 0 || ix >= W) continue;
-            s += mask[((int64_t)b * H + iy) * W + ix];
+    if (k == 3) {
+        // the pyramid's levels are all 3x3 (enc4-7, dec1-7): nine unconditional loads at clamped addresses, in flight together,
+        // summed in the same order with zeros for the taps outside (s + 0 = s: the same bits) -- the rolled, branchy loop below
+        // awaited one L2 round trip per tap, nine in a row per level of a 16-level dependent chain
+        float v[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = oy * stride - pad + t / 3, ix = ox * stride - pad + t % 3;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float m = mask[((int64_t)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)];
+            v[t] = ok ? m : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s += v[t];
+    } else {
+        for (int ky = 0; ky < k; ++ky) {
+            const int iy = oy * stride - pad + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ix = ox * stride - pad + kx;
+                if (ix < 0 || ix >= W) continue;
+                s += mask[((int64_t)b * H + iy) * W + ix];
+            }
         }
     }
     const float on = s > 0.f ? 1.f : 0.f;

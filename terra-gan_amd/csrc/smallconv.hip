@@ -415,6 +415,81 @@ __global__ __launch_bounds__(256) void to1conv64_lds_kernel(const IGemmParams p,
 }
 
 
+// ---- 64 channels -> 1 channel, the FOUR 2x2-tap parity classes of a 4x4 stride-2 dgrad (D conv0's input gradient) from ONE LDS
+// patch.  to1conv64_multi22_kernel fetches every tap of every class straight from global memory: each dy pixel goes through the
+// texture path sixteen times (1 GB for 67 MB of dy: 60 us, 1.1 TB/s algorithmic).  Here a workgroup stages the (4+2) x (16+2) pixel
+// x 64 channel patch of a 4 x 16 tile of the class grid once (as to1conv64_lds_kernel does) and all four classes read their
+// taps from it; class c writes dst pixel (oy * ds + dy0_c, ox * ds + dx0_c).
+__global__ __launch_bounds__(256) void to1conv64_multi22_lds_kernel(const IGemmMulti pm, int tiles_x, int tiles_y, int sy_min, int sx_min) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [T1_PH][T1_PW][64]
+    const IGemmParams& p0 = pm.c[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = lane >> 4, cq = lane & 15;
+    int tile = blockIdx.x;
+    const int txi = tile % tiles_x;
+    tile /= tiles_x;
+    const int tyi = tile % tiles_y, b = tile / tiles_y;
+    const int oy0 = tyi * T1_TH, ox0 = txi * T1_TW;
+    constexpr int NSLOT = T1_PH * T1_PW * 16, NIT = (NSLOT + 255) / 256;
+    f32x4 v[NIT];
+    uint32_t inbits = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int slot = threadIdx.x + 256 * it, pp = slot >> 4;
+        const int py = pp / T1_PW, px = pp - py * T1_PW;
+        const int iy = oy0 + sy_min + py, ix = ox0 + sx_min + px;
+        const bool in = slot < NSLOT && iy >= 0 && iy < p0.IH && ix >= 0 && ix < p0.IW;
+        const size_t pix = in ? ((size_t)b * p0.IH + iy) * p0.IW + ix : 0;
+        v[it] = *reinterpret_cast<const f32x4*>(p0.src + pix * 64 + 4 * (slot & 15));
+        inbits |= (in ? 1u : 0u) << it;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int slot = threadIdx.x + 256 * it;
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (inbits >> it) & 1u ? v[it][k] : 0.f;
+        if (slot < NSLOT) *reinterpret_cast<f32x4*>(sm + 4 * slot) = o;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        const IGemmParams& p = pm.c[c];
+        f32x4 w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            w[t] = *reinterpret_cast<const f32x4*>(p.wmat + (size_t)weight_tap(p, t >> 1, t & 1) * 64 + 4 * cq);
+        const float bias = p.bias ? p.bias[0] : 0.f;
+        const int oyy = p.sy0 - sy_min, oxx = p.sx0 - sx_min;
+#pragma unroll 2
+        for (int seg = 0; seg < T1_TW / 4; ++seg) {
+            const int tx_o = 4 * seg + e;
+            const float* pb = sm + (((wave + oyy) * T1_PW) + tx_o + oxx) * 64 + 4 * cq;
+            float acc = 0.f;
+#pragma unroll
+            for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < 2; ++tx) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(pb + ((ty * p.tstep) * T1_PW + tx * p.tstep) * 64);
+                    const f32x4 ww = w[ty * 2 + tx];
+                    acc += x[0] * ww[0] + x[1] * ww[1] + x[2] * ww[2] + x[3] * ww[3];
+                }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            const int oy = oy0 + wave, ox = ox0 + tx_o;
+            if (cq == 0 && oy < p.OH && ox < p.OW) {
+                const size_t opix = out_pixel(p, b, oy, ox);
+                float r = acc + bias;
+                if (p.rowscale) r *= p.rowscale[opix];
+                r = apply_act(r, p.act, p.slope);
+                if (p.gate) r *= gate_factor(p, opix);
+                if (p.accumulate) r += p.dst[opix];
+                p.dst[opix] = r;
+            }
+        }
+    }
+}
+
 // ---- C channels -> 1 channel for WIDE C (C % 256 == 0: the discriminator's last conv, 512 -> 1, 4x4) ---------------------------
 // A wave owns one output pixel at a time: lane = channel quad j*64 + lane of every 256-channel group, so a tap of one pixel is
 // C/256 coalesced 1 KB rows; the lane's weights (taps x C/256 quads) live in registers for the whole launch and the channel
@@ -506,6 +581,30 @@ bool smallconv_to1_multi_applies(const IGemmParams* cls, int ncls) {
 int smallconv_to1_multi_launch(const IGemmParams* cls, int ncls, hipStream_t s) {
     IGemmMulti pm = {};
     for (int i = 0; i < ncls; ++i) pm.c[i] = cls[i];
+    {
+        // one LDS patch for the four classes: they must read the same source tensor within a (T + 2)-pixel window, unmasked
+        static const bool no_lds = getenv("TG_NO_TO1LDS") != nullptr || getenv("TG_NO_TO1_MULTI_LDS") != nullptr;
+        int sy_min = 1 << 30, sx_min = 1 << 30, sy_max = -(1 << 30), sx_max = -(1 << 30);
+        bool ok = !no_lds && cls[0].OH >= T1_TH && cls[0].OW >= T1_TW;
+        for (int i = 0; i < ncls; ++i) {
+            const IGemmParams& p = cls[i];
+            ok = ok && p.src == cls[0].src && p.IH == cls[0].IH && p.IW == cls[0].IW && p.B == cls[0].B && p.ss == 1 && !p.amask &&
+                 (p.tstep == 1 || p.tstep == -1);
+            for (int t = 0; t < 2; ++t) {
+                const int y = p.sy0 + t * p.tstep, x = p.sx0 + t * p.tstep;
+                sy_min = y < sy_min ? y : sy_min; sy_max = y > sy_max ? y : sy_max;
+                sx_min = x < sx_min ? x : sx_min; sx_max = x > sx_max ? x : sx_max;
+            }
+        }
+        if (ok && sy_max - sy_min <= 2 && sx_max - sx_min <= 2) {
+            const int tiles_x = cdiv(cls[0].OW, T1_TW), tiles_y = cdiv(cls[0].OH, T1_TH);
+            const size_t lds = (size_t)T1_PH * T1_PW * 64 * sizeof(float);
+            hipLaunchKernelGGL(to1conv64_multi22_lds_kernel, dim3(tiles_x * tiles_y * cls[0].B), dim3(256), lds, s, pm, tiles_x, tiles_y,
+                               sy_min, sx_min);
+            TG_CHECK_LAUNCH("to1conv64_multi22_lds_kernel");
+            return TG_OK;
+        }
+    }
     int blocks = cdiv(cls[0].M / 4, 4 * 4);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;

@@ -46,6 +46,8 @@ CONVS = [  # B, H, W, Cin, Cout, k, s, p
     (2, 16, 32, 1, 64, 3, 1, 1),      # 1 -> 64 (c1conv)
     (2, 16, 32, 64, 1, 3, 1, 1),      # 64 -> 1 (to1conv64)
     (2, 12, 20, 1, 128, 4, 2, 1),     # 1 -> 128, two channel groups
+    (2, 32, 40, 1, 64, 4, 2, 1),      # 1 -> 64 (D conv0): its dgrad = four 2x2-tap classes from one LDS patch (ragged: 16 x 20 class grid)
+    (3, 16, 32, 1, 64, 4, 2, 1),      # the same with whole tiles
     (3, 16, 16, 512, 1, 4, 1, 1),     # 512 -> 1, 4x4 (the discriminator's last conv: to1convw / to1wgradw)
     (2, 9, 13, 256, 1, 3, 1, 1),      # 256 -> 1, 3x3, odd sizes
 ]

@@ -267,6 +267,15 @@ def main():
             if os.path.exists(os.path.join(ROOT, "profiles", tname)):
                 traffic_src = "profiles/" + tname
                 break
+        # ... except at the workload that profile was taken on (the default: fp32, 256 x 256, batch 16, one GPU), where the
+        # committed per-launch figure of the dominant kernel is repeated here (bytes; FROM THE PROFILE, not from this run)
+        if traffic_src and args.precision == "f32" and args.batch == BATCH and args.size == TILE and world == 1 and not args.checkpoint:
+            try:
+                import json as _json
+                with open(os.path.join(ROOT, traffic_src)) as _f:
+                    traffic = round(float(_json.load(_f)["wino_kernel"]["hbm_bytes_per_launch"]))
+            except (OSError, KeyError, ValueError):
+                traffic = None
         common = {"traffic": traffic, "traffic_profile": traffic_src,
                   "effective_tflops": round(fl / sec / 1e12, 2) if ms > 0 else 0.0,
                   "launches_per_step": n // nprobe, "avg_launch_ms": round(ms / max(n, 1), 4),

@@ -1412,7 +1412,7 @@ static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, 
         TG_REQUIRE(g && x && y && prep >= 0 && (g->Ho % 2) == 0 && (g->Wo % 2) == 0 && aligned16(pool_y),
                    "tg_conv_fwd_pool: even output sizes and a 16-byte aligned pool_y expected");
         int fused = 0;
-        if (!s2d_ok(g) && !wino22_fwd_geom_ok(g) && g->precision != TG_PREC_BF16) {
+        if (!s2d_ok(g) && !wino22_fwd_geom_ok(g)) {
             g_pool_request = pool_y;
             g_pool_fused = 0;
             const int rc1 = conv_fwd_impl(g, x, in_mask, w, wprep, prep, bias, ratio, act, slope, y, ws, ws_bytes, stream);

@@ -307,3 +307,21 @@ def test_wino16_wgrad(dev, case):
     dw2, _ = O.conv_wgrad(x.to(dev), dy.to(dev), w, k, s_, pad)
     assert torch.equal(dw, dw2)
     O.set_precision("f32")
+
+
+@pytest.mark.parametrize("case", [(8, 128, 128, 64, 64), (4, 96, 96, 64, 128), (3, 40, 24, 16, 64)])
+def test_bf16_conv_fwd_pool_equals_conv_then_pool(dev, case):
+    """bf16 mode: the pooled tensor of tg_conv_fwd_pool (wino16_pipe_kernel<.., POOL>) and the conv output next to it equal
+    tg_conv_fwd_p + tg_maxpool2_fwd bit for bit."""
+    from tg_hip import ops as O
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).contiguous(memory_format=torch.channels_last).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    O.set_precision("bf16")
+    y0 = O.conv_fwd(x, w, b, 3, 1, 1, act=O.ACT_RELU)
+    p0 = O.maxpool2_fwd(y0)
+    y1, p1 = O.conv_fwd(x, w, b, 3, 1, 1, act=O.ACT_RELU, pool=True)
+    assert torch.equal(y1, y0) and torch.equal(p1, p0), float((p1 - p0).abs().max())
+    assert float(p1.abs().sum()) > 0

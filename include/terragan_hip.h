@@ -106,6 +106,17 @@ int tg_conv_fwd_p(const TgConv* g, const float* x, const float* in_mask, const f
 int tg_conv_fwd_pool(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* wprep,
                      const float* bias, const float* ratio, int act, float slope, float* y, float* pool_y, float* ws,
                      size_t ws_bytes, tg_stream_t stream);
+/* conv -> ReLU -> MaxPool2d(2) where the full-resolution conv output has no other reader than the pool and the pool's backward
+ * (torchvision vgg16().features[2..4] and [7..9], losses.py:31-34,79-90): writes the pooled tensor [B][Ho/2][Wo/2][Cout] and one
+ * CODE byte per pooled element and channel (bits 0-1: window position 2*row + column of the maximum, the first one as in ATen;
+ * bit 2: maximum > 0, i.e. the ReLU gate) -- the conv output itself is never written.  tg_maxpool2_bwd_code turns the pooled
+ * gradient + code into the full-resolution gradient in front of the ReLU.  Only where the fp32 Winograd kernel takes the
+ * launch in one K split: tg_conv_pool_code_supported (callers fall back to tg_conv_fwd_pool / tg_maxpool2_bwd). */
+int tg_conv_pool_code_supported(const TgConv* g);
+int tg_conv_fwd_pool_code(const TgConv* g, const float* x, const float* w, const float* wprep, const float* bias,
+                          float* pool_y, unsigned char* code, float* ws, size_t ws_bytes, tg_stream_t stream);
+int tg_maxpool2_bwd_code(const float* dout, const unsigned char* code, int B, int Ho, int Wo, int C, float* dx,
+                         tg_stream_t stream);
 /* BatchNorm + activation on load: the layer's input is act(BN(x)) -- x the PRE-BatchNorm output of the layer below, statistics
  * and affine parameters in `bn` -- and that tensor is never written.  For `final` (generator.py:29,56: Conv2d(64, 1, 3, 1, 1) over
  * dec1's ReLU(BN(.)) output, pconv.py:43-48): saves dec1's BatchNorm-apply pass (one read + one write of the widest activation).

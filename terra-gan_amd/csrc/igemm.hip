@@ -1403,6 +1403,7 @@ extern "C" size_t tg_conv_wprep_bytes(const TgConv* g, int mode) {
 static thread_local float* g_pool_request = nullptr;
 static thread_local int g_pool_fused = 0;
 static thread_local const BnIn* g_bnin_request = nullptr;      // tg_conv_fwd_bnin
+static thread_local unsigned char* g_pool_code_request = nullptr;      // tg_conv_fwd_pool_code (with g_pool_request; dst not written)
 static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, const float* w, float* wprep, int prep,
                          const float* bias, const float* ratio, int act, float slope, float* y, float* ws, size_t ws_bytes,
                          tg_stream_t stream, float* pool_y = nullptr) {
@@ -1512,6 +1513,8 @@ static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, 
     }
     if (prep < 0 && !p.wino_u) return TG_OK;              // this layer runs on the raw weights: nothing to prepare
     p.pool_dst = g_pool_request;
+    p.pool_code = g_pool_code_request;
+    p.pool_only = g_pool_code_request != nullptr;
     if (g_bnin_request) {
         p.in_bn = *g_bnin_request;
         TG_REQUIRE(smallconv_bnin_fwd_ok(p), "tg_conv_fwd_bnin: geometry not supported (ask tg_conv_bnin_supported first)");
@@ -1527,6 +1530,34 @@ extern "C" int tg_conv_fwd_pool(const TgConv* g, const float* x, const float* in
     TG_REQUIRE(pool_y, "tg_conv_fwd_pool: null pointer");
     return conv_fwd_impl(g, x, in_mask, w, const_cast<float*>(wprep), wprep ? 1 : 0, bias, ratio, act, slope, y, ws, ws_bytes, stream,
                          pool_y);
+}
+// conv -> ReLU -> 2x2 max-pool where the full-resolution conv output has no reader but the pool and the pool's backward
+// (VGG16 features[2..4], [7..9]): pooled tensor + one code byte per pooled element (IGemmParams::pool_code), the conv output
+// itself is never written.  Only where wino_pipe_kernel<.., POOL> takes the launch in one K split.
+extern "C" int tg_conv_pool_code_supported(const TgConv* g) {
+    if (!g || g->precision != TG_PREC_F32 || !wino_fwd_geom_ok(g) || s2d_ok(g) || (g->Ho & 1) || (g->Wo & 1)) return 0;
+    if (getenv("TG_NO_FUSED_POOL") || getenv("TG_NO_POOL_CODE") || getenv("TG_WINO_NO_PIPE") || getenv("TG_WINO_NO_FAST")) return 0;
+    if ((size_t)g->B * g->Ho * g->Wo * g->Cout * 4 >= ((size_t)1 << 31) || (size_t)g->B * g->H * g->W * g->Cin * 4 >= ((size_t)1 << 31)) return 0;
+    const int nchunks = g->Cin / 8;
+    if (nchunks < 2) return 0;
+    const long work = (long)cdiv(g->Wo, 16) * cdiv(g->Ho, 16) * g->B * (g->Cout / WINO_BN);
+    return nchunks < 16 || work >= 4L * WINO_PLAN_CUS ? 1 : 0;         // (launch_wino: one K split)
+}
+extern "C" int tg_conv_fwd_pool_code(const TgConv* g, const float* x, const float* w, const float* wprep, const float* bias,
+                                     float* pool_y, unsigned char* code, float* ws, size_t ws_bytes, tg_stream_t stream) {
+    TG_REQUIRE(pool_y && code && aligned16(pool_y) && (reinterpret_cast<uintptr_t>(code) & 3) == 0, "tg_conv_fwd_pool_code: bad pointers");
+    TG_REQUIRE(tg_conv_pool_code_supported(g), "tg_conv_fwd_pool_code: geometry not supported (ask tg_conv_pool_code_supported first)");
+    g_pool_request = pool_y;
+    g_pool_code_request = code;
+    g_pool_fused = 0;
+    // (dst is not written: the pooled buffer stands in for the pointer checks)
+    const int rc = conv_fwd_impl(g, x, nullptr, w, const_cast<float*>(wprep), wprep ? 1 : 0, bias, nullptr, TG_ACT_RELU, 0.f, pool_y, ws,
+                                 ws_bytes, stream);
+    g_pool_request = nullptr;
+    g_pool_code_request = nullptr;
+    if (rc) return rc;
+    TG_REQUIRE(g_pool_fused, "tg_conv_fwd_pool_code: internal: the launch did not take the fused path");
+    return TG_OK;
 }
 static bool bnin_geom_ok(const TgConv* g) {
     return g && g->Cout == 1 && g->Cin == 64 && g->k == 3 && g->stride == 1 && g->pad == 1 && (g->Wo % 4) == 0;

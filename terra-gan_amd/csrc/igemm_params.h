@@ -43,6 +43,11 @@ struct IGemmParams {
     // [B][OH/2][OW/2][N].  A launcher that writes it sets pool_done; otherwise the caller runs the pool kernel on dst.
     float* pool_dst;
     int pool_done;
+    // tg_conv_fwd_pool_code: with the pooled tensor a BYTE per pooled element and channel -- bits 0-1 the window position of the
+    // maximum (2*row + column, first maximum wins as in ATen), bit 2 "maximum > 0" (the ReLU gate) -- which is all the pool's
+    // backward needs; pool_only: dst itself is NOT written (its only readers were the pool and that backward)
+    unsigned char* pool_code;
+    int pool_only;
     BnIn in_bn;             // (the 64 -> 1 channel LDS-patch kernel only: `final`, smallconv.hip)
 };
 __device__ __forceinline__ float gate_factor(const IGemmParams& p, size_t idx) {

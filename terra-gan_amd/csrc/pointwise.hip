@@ -1573,6 +1573,42 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
         }
     }
 }
+// backward of the fused conv -> ReLU -> max-pool from the pool's CODE (tg_conv_fwd_pool_code: bits 0-1 window position of the
+// maximum, bit 2 "maximum > 0"): one thread per pooled pixel and channel quad reads 16 B of gradient + 4 B of code and writes the
+// window's four quads -- the full-resolution activation is not read (it was never written)
+__global__ __launch_bounds__(256) void maxpool2_bwd_code_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ code, int B,
+                                                                int Ho, int Wo, int C, float* __restrict__ dx) {
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)B * Ho * Wo * c4n;
+    const int64_t rowpitch = (int64_t)2 * Wo * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % c4n) * 4;
+        const int64_t pp = idx / c4n;                 // pooled pixel (b, oy, ox)
+        const int ox = (int)(pp % Wo);
+        const int64_t t = pp / Wo;
+        const int oy = (int)(t % Ho), b = (int)(t / Ho);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dout + pp * C + c);
+        const uint32_t cd = *reinterpret_cast<const uint32_t*>(code + pp * C + c);
+        float* base = dx + (((int64_t)b * 2 * Ho + 2 * oy) * 2 * Wo + 2 * ox) * C + c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t ce = (cd >> (8 * e)) & 0xffu;
+                o[e] = ((ce & 3u) == (uint32_t)k && (ce & 4u)) ? d[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(base + (k >> 1) * rowpitch + (k & 1) * C) = o;
+        }
+    }
+}
+extern "C" int tg_maxpool2_bwd_code(const float* dout, const unsigned char* code, int B, int Ho, int Wo, int C, float* dx, tg_stream_t stream) {
+    TG_REQUIRE(dout && code && dx && B > 0 && Ho > 0 && Wo > 0 && C > 0 && (C % 4) == 0, "tg_maxpool2_bwd_code: bad arguments");
+    hipLaunchKernelGGL(maxpool2_bwd_code_kernel, dim3(ew_grid((int64_t)B * Ho * Wo * (C / 4), 256)), dim3(256), 0, S(stream), dout, code, B, Ho,
+                       Wo, C, dx);
+    TG_CHECK_LAUNCH("maxpool2_bwd_code_kernel");
+    return TG_OK;
+}
 extern "C" int tg_maxpool2_bwd(const float* dout, const float* x, int B, int H, int W, int C, int relu_gate, float* dx,
                                tg_stream_t stream) {
     TG_REQUIRE(dout && x && dx && B > 0 && H > 1 && W > 1 && C > 0, "tg_maxpool2_bwd: bad arguments");

@@ -56,6 +56,7 @@ VGG_TRUNK = [0, 2, "M", 5, 7, "M", 10, 12, 14]
 VGG_WINO4 = os.environ.get("TG_VGG_WINO4", "1") != "0"
 VGG_WINO4_FWD = os.environ.get("TG_VGG_WINO4_FWD", "0") == "1"
 VGG_WINO4_MINCH = int(os.environ.get("TG_VGG_WINO4_MINCH", "128"))
+POOL_CODE = os.environ.get("TG_NO_POOL_CODE") is None       # pooled convs of the trunk: pooled tensor + pool code, no full-resolution output
 
 
 def _vgg_wino4(w, B, H, W, cout, mode=None, default=True):
@@ -477,22 +478,28 @@ def vgg_forward(V, img, keep=True, wino4=None):
     force F(4x4,3x3) on (wherever the geometry allows) / off."""
     h = img.reshape(*img.shape, 1)
     steps = []
-    pooled = None
+    pooled = code = None
     for i, item in enumerate(VGG_TRUNK):
         if item == "M":
             # (the conv below has written the pooled tensor with its own output where the sizes are even)
             o = pooled if pooled is not None else O.maxpool2_fwd(h)
-            pooled = None
             if keep:
-                steps.append(NS(kind="M", x=h))
+                steps.append(NS(kind="M", x=h, code=code))
+            pooled = code = None
         else:
             w = V["0.folded"] if item == 0 else V[f"{item}.weight"]
             O.tag(f"vgg{item}.fwd")
             pool = i + 1 < len(VGG_TRUNK) and VGG_TRUNK[i + 1] == "M" and h.shape[1] % 2 == 0 and h.shape[2] % 2 == 0
-            o = O.conv_fwd(h, w, V[f"{item}.bias"], 3, 1, 1, act=O.ACT_RELU, pool=pool,
-                           wino4=_vgg_wino4(w, h.shape[0], h.shape[1], h.shape[2], w.shape[0], wino4, VGG_WINO4_FWD))
-            if pool:
-                o, pooled = o
+            w4 = _vgg_wino4(w, h.shape[0], h.shape[1], h.shape[2], w.shape[0], wino4, VGG_WINO4_FWD)
+            if pool and POOL_CODE and not w4 and O.conv_pool_code_supported(tuple(h.shape), w.shape[0]):
+                # the full-resolution output of a pooled conv has two readers, the pool and the pool's backward: it is not written
+                # at all -- the pooled tensor and a byte of (arg-max position, ReLU gate) per pooled element leave the conv instead
+                pooled, code = O.conv_fwd_pool_code(h, w, V[f"{item}.bias"])
+                o = None
+            else:
+                o = O.conv_fwd(h, w, V[f"{item}.bias"], 3, 1, 1, act=O.ACT_RELU, pool=pool, wino4=w4)
+                if pool:
+                    o, pooled = o
             if keep:
                 steps.append(NS(kind="C", w=w, x_shape=tuple(h.shape), a=o))
         h = o
@@ -510,11 +517,14 @@ def vgg_backward(ctx, dfeat, nb=None, wino4=None, gated=False):
         st = steps[i]
         if st.kind == "M":
             # the pooled tensor is a ReLU output: its backward is fused into the pool backward
-            x = st.x if nb is None else st.x[:nb]
-            da = O.maxpool2_bwd(da, x, relu_gate=True)
+            if getattr(st, "code", None) is not None:
+                da = O.maxpool2_bwd_code(da, st.code)        # (code of all the forward's images: the first nb are read)
+            else:
+                x = st.x if nb is None else st.x[:nb]
+                da = O.maxpool2_bwd(da, x, relu_gate=True)
             gated = True
         else:
-            a = st.a if nb is None else st.a[:nb]
+            a = None if st.a is None else (st.a if nb is None else st.a[:nb])      # (None: a pooled conv under the pool-code path)
             dy = da if gated else O.act_bwd(da, a, O.ACT_RELU)
             shp = st.x_shape if nb is None else (nb,) + tuple(st.x_shape[1:])
             below = steps[i - 1] if i > 0 else None

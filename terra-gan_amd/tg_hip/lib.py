@@ -57,6 +57,9 @@ SIGNATURES = {
     "tg_conv_wprep_run": (I, [P, I, P]),
     "tg_conv_fwd_p": (I, [CP, P, P, P, P, P, P, I, F, P, P, SZ, P]),
     "tg_conv_fwd_pool": (I, [CP, P, P, P, P, P, P, I, F, P, P, P, SZ, P]),
+    "tg_conv_pool_code_supported": (I, [CP]),
+    "tg_conv_fwd_pool_code": (I, [CP, P, P, P, P, P, P, P, SZ, P]),
+    "tg_maxpool2_bwd_code": (I, [P, P, I, I, I, I, P, P]),
     "tg_conv_bnin_supported": (I, [CP, I]),
     "tg_conv_fwd_bnin": (I, [CP, P, C.POINTER(TgBnAct), P, P, I, F, P, P, SZ, P]),
     "tg_conv_wgrad_bnin": (I, [CP, P, C.POINTER(TgBnAct), P, P, P, P, SZ, P]),

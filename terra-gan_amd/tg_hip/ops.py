@@ -259,6 +259,39 @@ def conv_fwd_bnin(x, in_bn, w, bias, k, stride, pad, act=ACT_NONE, slope=0.0):
     return y
 
 
+def conv_pool_code_supported(x_shape, cout):
+    """Can conv_fwd_pool_code take this 3x3 / stride-1 / pad-1 layer (pooled tensor + code, conv output never written)?"""
+    B, H, W, Cin = x_shape
+    g = L.TgConv(B, H, W, Cin, H, W, cout, 3, 1, 1, _precision)
+    return bool(_lib().tg_conv_pool_code_supported(C.byref(g)))
+
+
+def conv_fwd_pool_code(x, w, bias):
+    """3x3 / stride-1 / pad-1 conv -> ReLU -> 2x2 max-pool: returns (pooled, code); the full-resolution output is not written
+    (tg_conv_fwd_pool_code).  code: uint8 [B][H/2][W/2][Cout], consumed by maxpool2_bwd_code."""
+    _chk(x, "x"); _chk(bias, "bias")
+    wv = weight_view(w)
+    _chk(wv, "weight")
+    g = conv_geom(x, wv.shape[0], 3, 1, 1)
+    yp = empty(g.B, g.Ho // 2, g.Wo // 2, g.Cout, like=x)
+    code = torch.empty((g.B, g.Ho // 2, g.Wo // 2, g.Cout), dtype=torch.uint8, device=x.device)
+    lib = _lib()
+    ws = workspace(lib.tg_conv_fwd_ws_bytes(C.byref(g)))
+    L.check(lib.tg_conv_fwd_pool_code(C.byref(g), _p(x), _p(wv), _p(_prepared(w, wv, g, WPREP_FWD)), _p(bias), _p(yp),
+                                      C.c_void_p(code.data_ptr()), _p(ws), ws.numel() * 4, _stream()), "tg_conv_fwd_pool_code")
+    return yp, code
+
+
+def maxpool2_bwd_code(dout, code):
+    """Gradient in front of the fused conv's ReLU from the pooled gradient and the pool code: [B][2 Ho][2 Wo][C]."""
+    _chk(dout, "dout")
+    B, Ho, Wo, Cc = dout.shape
+    assert code.dtype == torch.uint8 and code.is_contiguous() and tuple(code.shape[1:]) == (Ho, Wo, Cc) and code.shape[0] >= B
+    dx = empty(B, 2 * Ho, 2 * Wo, Cc, like=dout)
+    L.check(_lib().tg_maxpool2_bwd_code(_p(dout), C.c_void_p(code.data_ptr()), B, Ho, Wo, Cc, _p(dx), _stream()), "tg_maxpool2_bwd_code")
+    return dx
+
+
 def conv_dgrad(dy, w, x_shape, k, stride, pad, in_mask=None, out=None, gate=None, gate_act=ACT_RELU, gate_slope=0.0, wino4=False):
     """dx for an input of shape x_shape=[B,H,W,Cin]; accumulates into `out` when given.  `gate` = output of the
     activation that produced x: its backward is fused into the epilogue (dx *= act'(gate))."""

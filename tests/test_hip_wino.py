@@ -608,3 +608,29 @@ def test_conv_fwd_pool_is_fused_on_the_trunk_layers(dev, tmp_path):
     assert abs(float(rows[0]["alg_mb"]) - (plain_mb + 4 * yp.numel() / 1e6)) < 1e-2 * plain_mb, (rows[0]["alg_mb"], plain_mb)
     assert torch.equal(yp, O.maxpool2_fwd(y))
     assert float(yp.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("case", [(32, 128, 128, 64, 64), (16, 96, 96, 64, 128), (40, 48, 80, 24, 64)])
+def test_conv_fwd_pool_code_and_its_backward(dev, case):
+    """tg_conv_fwd_pool_code: the pooled tensor equals conv + ReLU + max-pool bit for bit, and tg_maxpool2_bwd_code applied to the
+    code reproduces tg_maxpool2_bwd(relu_gate) on the full-resolution activation -- which this path never writes."""
+    from tg_hip import ops as O
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    x[:, : H // 4] = 0                                   # a band of exact zeros: windows whose maximum is 0 (gate closed, ties)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).contiguous(memory_format=torch.channels_last).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    b[: Cout // 2] = -0.5                                # ... and channels that are negative there before the ReLU
+    assert O.conv_pool_code_supported(tuple(x.shape), Cout)
+    y = O.conv_fwd(x, w, b, 3, 1, 1, act=O.ACT_RELU)
+    p0 = O.maxpool2_fwd(y)
+    p1, code = O.conv_fwd_pool_code(x, w, b)
+    assert torch.equal(p1, p0)
+    dp = torch.randn(p0.shape, generator=g).to(dev)
+    nb = B // 2
+    dx0 = O.maxpool2_bwd(dp[:nb].contiguous(), y[:nb], relu_gate=True)
+    dx1 = O.maxpool2_bwd_code(dp[:nb].contiguous(), code)
+    assert torch.equal(dx1, dx0), float((dx1 - dx0).abs().max())
+    assert float(dx1.abs().sum()) > 0 and float((dx1 == 0).float().mean()) > 0.75
+    assert not O.conv_pool_code_supported((2, 32, 32, 128), 128)          # a K-split plan: stays on the two-output form

@@ -1535,10 +1535,10 @@ extern "C" int tg_conv_fwd_pool(const TgConv* g, const float* x, const float* in
 // (VGG16 features[2..4], [7..9]): pooled tensor + one code byte per pooled element (IGemmParams::pool_code), the conv output
 // itself is never written.  Only where wino_pipe_kernel<.., POOL> takes the launch in one K split.
 extern "C" int tg_conv_pool_code_supported(const TgConv* g) {
-    if (!g || g->precision != TG_PREC_F32 || !wino_fwd_geom_ok(g) || s2d_ok(g) || (g->Ho & 1) || (g->Wo & 1)) return 0;
+    if (!g || (g->precision != TG_PREC_F32 && g->precision != TG_PREC_BF16) || !wino_fwd_geom_ok(g) || s2d_ok(g) || (g->Ho & 1) || (g->Wo & 1)) return 0;
     if (getenv("TG_NO_FUSED_POOL") || getenv("TG_NO_POOL_CODE") || getenv("TG_WINO_NO_PIPE") || getenv("TG_WINO_NO_FAST")) return 0;
     if ((size_t)g->B * g->Ho * g->Wo * g->Cout * 4 >= ((size_t)1 << 31) || (size_t)g->B * g->H * g->W * g->Cin * 4 >= ((size_t)1 << 31)) return 0;
-    const int nchunks = g->Cin / 8;
+    const int nchunks = g->Cin / wino_kc(g);            // K steps of 8 (fp32) / 16 (bf16 operands) channels
     if (nchunks < 2) return 0;
     const long work = (long)cdiv(g->Wo, 16) * cdiv(g->Ho, 16) * g->B * (g->Cout / WINO_BN);
     return nchunks < 16 || work >= 4L * WINO_PLAN_CUS ? 1 : 0;         // (launch_wino: one K split)

@@ -325,3 +325,25 @@ def test_bf16_conv_fwd_pool_equals_conv_then_pool(dev, case):
     y1, p1 = O.conv_fwd(x, w, b, 3, 1, 1, act=O.ACT_RELU, pool=True)
     assert torch.equal(y1, y0) and torch.equal(p1, p0), float((p1 - p0).abs().max())
     assert float(p1.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("case", [(16, 128, 128, 64, 64), (8, 96, 96, 128, 128)])
+def test_bf16_conv_fwd_pool_code_and_its_backward(dev, case):
+    """bf16 mode of tg_conv_fwd_pool_code / tg_maxpool2_bwd_code: same pooled tensor and same pool backward as the two-output form."""
+    from tg_hip import ops as O
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    x[:, : H // 4] = 0
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).contiguous(memory_format=torch.channels_last).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    b[: Cout // 2] = -0.5
+    O.set_precision("bf16")
+    assert O.conv_pool_code_supported(tuple(x.shape), Cout)
+    y = O.conv_fwd(x, w, b, 3, 1, 1, act=O.ACT_RELU)
+    p0 = O.maxpool2_fwd(y)
+    p1, code = O.conv_fwd_pool_code(x, w, b)
+    assert torch.equal(p1, p0)
+    dp = torch.randn(p0.shape, generator=g).to(dev)
+    nb = B // 2
+    assert torch.equal(O.maxpool2_bwd_code(dp[:nb].contiguous(), code), O.maxpool2_bwd(dp[:nb].contiguous(), y[:nb], relu_gate=True))

@@ -1652,17 +1652,20 @@ extern "C" size_t tg_pixel_loss_ws_bytes(int B, int H, int W) { return tg_reduce
 
 // ---- pixel-space losses -------------------------------------------------------------------------------
 __device__ __forceinline__ float band_at(const float* __restrict__ m, int b, int y, int x, int H, int W) {
-    float mx = -INFINITY, mn = INFINITY;
-    for (int dy = -1; dy <= 1; ++dy) {
-        int yy = y + dy;
-        if (yy < 0 || yy >= H) continue;
-        for (int dx = -1; dx <= 1; ++dx) {
-            int xx = x + dx;
-            if (xx < 0 || xx >= W) continue;
-            float v = m[((int64_t)b * H + yy) * W + xx];
-            mx = fmaxf(mx, v);
-            mn = fminf(mn, v);
-        }
+    // nine unconditional loads at CLAMPED coordinates, all in flight: a clamped tap repeats a pixel that is inside the window
+    // anyway, so the maximum and the minimum over the in-range taps are unchanged (the rolled loop with its `continue`s awaited
+    // one load after the other: 29 us for a 1 M-pixel pass)
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = min(max(y + t / 3 - 1, 0), H - 1), xx = min(max(x + t % 3 - 1, 0), W - 1);
+        v[t] = m[((int64_t)b * H + yy) * W + xx];
+    }
+    float mx = v[0], mn = v[0];
+#pragma unroll
+    for (int t = 1; t < 9; ++t) {
+        mx = fmaxf(mx, v[t]);
+        mn = fminf(mn, v[t]);
     }
     // dilated - eroded, eroded = 1 - maxpool(1 - m) = min(m) over the window (losses.py:406-408)
     float d = mx - (1.f - (1.f - mn));

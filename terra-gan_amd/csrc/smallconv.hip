@@ -514,20 +514,33 @@ __global__ __launch_bounds__(256) void to1convw_kernel(const IGemmParams p) {
         for (int ty = 0; ty < TH_; ++ty) {
             const int iy = oy * p.ss + p.sy0 + ty * p.tstep;
             if (iy < 0 || iy >= p.IH) continue;                        // wave-uniform
+            // the taps of a kernel row: loads unconditional at clamped columns and in flight together, a tap outside the image
+            // is dropped by its factor (a branch per tap put each tap's loads in a basic block of their own: one round trip per
+            // tap, sixteen in a row per output of the discriminator's last conv)
+            f32x4 xr[TW_][CQ];
+            float fr[TW_];
 #pragma unroll
             for (int tx = 0; tx < TW_; ++tx) {
                 const int ix = ox * p.ss + p.sx0 + tx * p.tstep;
-                if (ix < 0 || ix >= p.IW) continue;
-                const size_t pix = ((size_t)b * p.IH + iy) * p.IW + ix;
-                const float f = p.amask ? p.amask[pix] : 1.f;
+                const bool okx = ix >= 0 && ix < p.IW;
+                const size_t pix = ((size_t)b * p.IH + iy) * p.IW + (okx ? ix : 0);
+                const float mk = p.amask ? p.amask[pix] : 1.f;
+                fr[tx] = okx ? mk : 0.f;
+#pragma unroll
+                for (int j = 0; j < CQ; ++j) xr[tx][j] = *reinterpret_cast<const f32x4*>(p.src + pix * p.C + 256 * j + 4 * lane);
+            }
+#pragma unroll
+            for (int tx = 0; tx < TW_; ++tx) {
+                const int ix = ox * p.ss + p.sx0 + tx * p.tstep;
+                if (ix < 0 || ix >= p.IW) continue;                    // (wave-uniform; keeps the summation order of the taps that exist)
                 float part = 0.f;
 #pragma unroll
                 for (int j = 0; j < CQ; ++j) {
-                    const f32x4 x = *reinterpret_cast<const f32x4*>(p.src + pix * p.C + 256 * j + 4 * lane);
+                    const f32x4 x = xr[tx][j];
                     const f32x4 ww = w[ty * TW_ + tx][j];
                     part += x[0] * ww[0] + x[1] * ww[1] + x[2] * ww[2] + x[3] * ww[3];
                 }
-                acc = fmaf(f, part, acc);
+                acc = fmaf(fr[tx], part, acc);
             }
         }
 #pragma unroll

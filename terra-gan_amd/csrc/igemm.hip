@@ -1399,14 +1399,16 @@ extern "C" size_t tg_conv_wprep_bytes(const TgConv* g, int mode) {
     return 0;
 }
 
-// (one host thread drives a stream's launches: the request travels to the launcher beside the parameters, like g_wprep_capture)
-static thread_local float* g_pool_request = nullptr;
-static thread_local int g_pool_fused = 0;
-static thread_local const BnIn* g_bnin_request = nullptr;      // tg_conv_fwd_bnin
-static thread_local unsigned char* g_pool_code_request = nullptr;      // tg_conv_fwd_pool_code (with g_pool_request; dst not written)
+// what a forward call may ask of its launcher beyond the plain convolution (tg_conv_fwd_pool / _pool_code / _bnin)
+struct FwdExtras {
+    float* pool_dst = nullptr;              // 2x2 max-pool of the output, written from the output transform where the kernel can
+    unsigned char* pool_code = nullptr;     // ... with the pool code, and dst itself NOT written
+    const BnIn* in_bn = nullptr;            // the source is act(BN(src)), applied on load
+    int pool_fused = 0;                     // out: the launcher wrote the pooled tensor
+};
 static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, const float* w, float* wprep, int prep,
                          const float* bias, const float* ratio, int act, float slope, float* y, float* ws, size_t ws_bytes,
-                         tg_stream_t stream, float* pool_y = nullptr) {
+                         tg_stream_t stream, float* pool_y = nullptr, FwdExtras* ex = nullptr) {
     if (pool_y) {
         // tg_conv_fwd_pool: the kernel that can write the pooled tensor from its output transform does (wino_pipe_kernel<.., POOL>);
         // every other route runs the pool kernel on y -- the same values either way (a maximum has no rounding)
@@ -1414,12 +1416,11 @@ static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, 
                    "tg_conv_fwd_pool: even output sizes and a 16-byte aligned pool_y expected");
         int fused = 0;
         if (!s2d_ok(g) && !wino22_fwd_geom_ok(g)) {
-            g_pool_request = pool_y;
-            g_pool_fused = 0;
-            const int rc1 = conv_fwd_impl(g, x, in_mask, w, wprep, prep, bias, ratio, act, slope, y, ws, ws_bytes, stream);
-            g_pool_request = nullptr;
+            FwdExtras e;
+            e.pool_dst = pool_y;
+            const int rc1 = conv_fwd_impl(g, x, in_mask, w, wprep, prep, bias, ratio, act, slope, y, ws, ws_bytes, stream, nullptr, &e);
             if (rc1) return rc1;
-            fused = g_pool_fused;
+            fused = e.pool_fused;
         } else if (int rc1 = conv_fwd_impl(g, x, in_mask, w, wprep, prep, bias, ratio, act, slope, y, ws, ws_bytes, stream)) {
             return rc1;
         }
@@ -1512,16 +1513,18 @@ static int conv_fwd_impl(const TgConv* g, const float* x, const float* in_mask, 
         }
     }
     if (prep < 0 && !p.wino_u) return TG_OK;              // this layer runs on the raw weights: nothing to prepare
-    p.pool_dst = g_pool_request;
-    p.pool_code = g_pool_code_request;
-    p.pool_only = g_pool_code_request != nullptr;
-    if (g_bnin_request) {
-        p.in_bn = *g_bnin_request;
-        TG_REQUIRE(smallconv_bnin_fwd_ok(p), "tg_conv_fwd_bnin: geometry not supported (ask tg_conv_bnin_supported first)");
+    if (ex) {
+        p.pool_dst = ex->pool_dst;
+        p.pool_code = ex->pool_code;
+        p.pool_only = ex->pool_code != nullptr;
+        if (ex->in_bn) {
+            p.in_bn = *ex->in_bn;
+            TG_REQUIRE(smallconv_bnin_fwd_ok(p), "tg_conv_fwd_bnin: geometry not supported (ask tg_conv_bnin_supported first)");
+        }
     }
     plan_splits(p, ws_floats);
     rc = launch_igemm(p, (hipStream_t)stream, ws_floats);
-    if (g_pool_request) g_pool_fused = p.pool_done;
+    if (ex) ex->pool_fused = p.pool_done;
     return rc;
 }
 extern "C" int tg_conv_fwd_pool(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* wprep,
@@ -1547,16 +1550,14 @@ extern "C" int tg_conv_fwd_pool_code(const TgConv* g, const float* x, const floa
                                      float* pool_y, unsigned char* code, float* ws, size_t ws_bytes, tg_stream_t stream) {
     TG_REQUIRE(pool_y && code && aligned16(pool_y) && (reinterpret_cast<uintptr_t>(code) & 3) == 0, "tg_conv_fwd_pool_code: bad pointers");
     TG_REQUIRE(tg_conv_pool_code_supported(g), "tg_conv_fwd_pool_code: geometry not supported (ask tg_conv_pool_code_supported first)");
-    g_pool_request = pool_y;
-    g_pool_code_request = code;
-    g_pool_fused = 0;
+    FwdExtras e;
+    e.pool_dst = pool_y;
+    e.pool_code = code;
     // (dst is not written: the pooled buffer stands in for the pointer checks)
     const int rc = conv_fwd_impl(g, x, nullptr, w, const_cast<float*>(wprep), wprep ? 1 : 0, bias, nullptr, TG_ACT_RELU, 0.f, pool_y, ws,
-                                 ws_bytes, stream);
-    g_pool_request = nullptr;
-    g_pool_code_request = nullptr;
+                                 ws_bytes, stream, nullptr, &e);
     if (rc) return rc;
-    TG_REQUIRE(g_pool_fused, "tg_conv_fwd_pool_code: internal: the launch did not take the fused path");
+    TG_REQUIRE(e.pool_fused, "tg_conv_fwd_pool_code: internal: the launch did not take the fused path");
     return TG_OK;
 }
 static bool bnin_geom_ok(const TgConv* g) {
@@ -1582,10 +1583,9 @@ extern "C" int tg_conv_fwd_bnin(const TgConv* g, const float* x, const TgBnAct* 
     TG_REQUIRE(bn && bn->mean && bn->rstd && bn->gamma && bn->beta, "tg_conv_fwd_bnin: null pointer");
     TG_REQUIRE(tg_conv_bnin_supported(g, 0), "tg_conv_fwd_bnin: geometry not supported (ask tg_conv_bnin_supported first)");
     const BnIn b = bnin_of(bn);
-    g_bnin_request = &b;
-    const int rc = conv_fwd_impl(g, x, nullptr, w, nullptr, 0, bias, nullptr, act, slope, y, ws, ws_bytes, stream);
-    g_bnin_request = nullptr;
-    return rc;
+    FwdExtras e;
+    e.in_bn = &b;
+    return conv_fwd_impl(g, x, nullptr, w, nullptr, 0, bias, nullptr, act, slope, y, ws, ws_bytes, stream, nullptr, &e);
 }
 extern "C" int tg_conv_fwd(const TgConv* g, const float* x, const float* in_mask, const float* w, const float* bias,
                            const float* ratio, int act, float slope, float* y, float* ws, size_t ws_bytes,
